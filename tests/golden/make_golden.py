@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Generates the golden vectors under tests/golden/ by running the REFERENCE quantizer.
+
+Run in the build container only (needs /root/reference):
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference module (vqvae/ema_vector_quantizer.py) is imported from /root/reference and
+executed on CPU; nothing of its source is stored, only inputs and outputs.  All inputs come
+from seeded NumPy PCG64 streams (helpers in tests/golden/inputs.py) so the tests can
+regenerate the large ones instead of storing them.
+
+Not generated here: the dict output of CustomVQGAN and analyze_codebook_utilization /
+monitor_codebook -- their modules import diffusers / torchvision, which this image lacks.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, "/root/reference")
+sys.dont_write_bytecode = True
+
+from inputs import gauss, ref_init_codebook  # noqa: E402
+from vqvae.ema_vector_quantizer import EMAVectorQuantizer  # noqa: E402  (the reference)
+
+torch.set_num_threads(4)
+
+
+def make_ref(K, D, beta, decay, E):
+    q = EMAVectorQuantizer(K, D, beta, decay=decay)
+    with torch.no_grad():
+        q.embedding.weight.copy_(torch.from_numpy(E))
+    return q
+
+
+def state_of(q):
+    sd = q.state_dict()
+    return {f"state_{k.replace('.', '_')}": v.detach().numpy().copy() for k, v in sd.items()}
+
+
+def run_step(q, z, T):
+    out = q(torch.from_numpy(z), temperature=T)
+    quant, loss, (perp, idx, enc) = out
+    assert enc.shape == (idx.shape[0], q.num_embeddings)
+    return {"quantized": quant.detach().numpy().copy(), "loss": np.float32(loss.item()),
+            "perplexity": np.float32(perp.item()), "indices": idx.numpy().astype(np.int64).copy()}
+
+
+def g1():
+    """Single step, K=512 D=64 N=128, train/eval, T in {1, 2.5}, two codebook inits."""
+    K, D = 512, 64
+    z = gauss(101, (2, D, 8, 8))
+    for init in ("gauss", "refinit"):
+        E = gauss(102, (K, D)) * np.float32(0.5) if init == "gauss" else ref_init_codebook(103, K, D)
+        for mode in ("train", "eval"):
+            for T in (1.0, 2.5):
+                q = make_ref(K, D, 3.0, 0.95, E)
+                q.train(mode == "train")
+                o = run_step(q, z, T)
+                stats = q.get_codebook_stats()
+                rec = {"z_seed": 101, "E": E, "T": np.float32(T), "beta": np.float32(3.0), "decay": np.float64(0.95),
+                       "training": np.bool_(mode == "train"), **o, **state_of(q),
+                       "stats": np.array([stats["active_size"], stats["utilization"], stats["entropy"],
+                                          stats["normalized_entropy"], stats["total_usage"]], np.float64)}
+                np.savez_compressed(os.path.join(HERE, f"g1_{init}_{mode}_T{T}.npz"), **rec)
+
+
+def g2():
+    """5-step EMA trajectory, fresh batch each step; pins the persisted Laplace smoothing."""
+    K, D = 128, 32
+    E0 = gauss(202, (K, D)) * np.float32(0.7)
+    for decay, beta, T in ((0.95, 3.0, 1.0), (0.7, 10.0, 2.5)):
+        q = make_ref(K, D, beta, decay, E0)
+        q.train(True)
+        rec = {"E0": E0, "decay": np.float64(decay), "beta": np.float32(beta), "T": np.float32(T),
+               "z_seeds": np.arange(210, 215)}
+        for step in range(5):
+            z = gauss(210 + step, (4, D, 8, 8))
+            o = run_step(q, z, T)
+            for k, v in o.items():
+                if k != "quantized":
+                    rec[f"s{step}_{k}"] = v
+            rec[f"s{step}_quantized_sum"] = np.float64(o["quantized"].astype(np.float64).sum())
+            for k, v in state_of(q).items():
+                rec[f"s{step}_{k}"] = v
+        np.savez_compressed(os.path.join(HERE, f"g2_traj_decay{decay}.npz"), **rec)
+
+
+def g3():
+    """Engineered ties: duplicated codebook rows and latents equidistant from two codes."""
+    K, D = 16, 8
+    E = np.zeros((K, D), np.float32)
+    E[:, 0] = np.arange(K, dtype=np.float32)          # codes on a line at 0,1,2,...
+    E[5] = E[3]                                         # exact duplicate of code 3
+    E[12] = E[3]
+    z = np.zeros((1, D, 4, 4), np.float32)
+    vals = np.array([3.0, 0.5, 1.5, 2.5, 7.5, 14.5, 100.0, -4.0, 3.0, 6.5, 9.5, 10.5, 0.0, 15.0, 8.0, 11.5], np.float32)
+    z[0, 0] = vals.reshape(4, 4)
+    q = make_ref(K, D, 1.0, 0.95, E)
+    q.eval()
+    o = run_step(q, z, 1.0)
+    np.savez_compressed(os.path.join(HERE, "g3_ties.npz"), E=E, z=z, **o)
+    # NaN / inf handling of torch.argmin on this path
+    z2 = z.copy()
+    z2[0, 1, 0, 0] = np.nan
+    z2[0, 2, 0, 1] = np.inf
+    z2[0, 3, 0, 2] = -np.inf
+    q = make_ref(K, D, 1.0, 0.95, E)
+    q.eval()
+    o = run_step(q, z2, 1.0)
+    np.savez_compressed(os.path.join(HERE, "g3_nonfinite.npz"), E=E, z=z2, indices=o["indices"])
+    # negative / zero temperature flips or degenerates the order (literal division, :49-50)
+    for T in (-1.0, 0.0):
+        q = make_ref(K, D, 1.0, 0.95, E)
+        q.eval()
+        o = run_step(q, z, T)
+        np.savez_compressed(os.path.join(HERE, f"g3_T{T}.npz"), E=E, z=z, T=np.float32(T), indices=o["indices"])
+
+
+def g4():
+    """Backward: d(a*sum(q*w) + b*loss)/dz for the straight-through + commitment term."""
+    K, D = 64, 16
+    E = gauss(402, (K, D)) * np.float32(0.6)
+    z = gauss(401, (2, D, 4, 4))
+    w = gauss(403, (2, D, 4, 4))
+    for mode in ("train", "eval"):
+        q = make_ref(K, D, 3.0, 0.95, E)
+        q.train(mode == "train")
+        zt = torch.from_numpy(z).requires_grad_(True)
+        quant, loss, _ = q(zt)
+        obj = 0.7 * (quant * torch.from_numpy(w)).sum() + 1.3 * loss
+        obj.backward()
+        np.savez_compressed(os.path.join(HERE, f"g4_backward_{mode}.npz"), E=E, z=z, w=w, a=np.float32(0.7),
+                            b=np.float32(1.3), beta=np.float32(3.0), grad=zt.grad.numpy().copy(),
+                            loss=np.float32(loss.item()))
+
+
+def g6():
+    """Full BASELINE config 1 (K=512, D=64, batch 16 of 16x16 latents): indices stored whole,
+    float outputs as float64 checksums; inputs are regenerated from their seeds."""
+    K, D = 512, 64
+    z = gauss(601, (16, D, 16, 16))
+    E = gauss(602, (K, D)) * np.float32(0.5)
+    q = make_ref(K, D, 3.0, 0.95, E)
+    q.train(True)
+    o = run_step(q, z, 1.0)
+    st = state_of(q)
+    rec = {"z_seed": 601, "E_seed": 602, "E_scale": np.float32(0.5), "indices": o["indices"].astype(np.int16),
+           "indices_sha256": hashlib.sha256(o["indices"].astype(np.int64).tobytes()).hexdigest(),
+           "loss": o["loss"], "perplexity": o["perplexity"],
+           "quantized_sum": np.float64(o["quantized"].astype(np.float64).sum()),
+           "quantized_abs_sum": np.float64(np.abs(o["quantized"].astype(np.float64)).sum())}
+    for k, v in st.items():
+        if v.ndim == 2:
+            rec[k + "_sum"] = np.float64(v.astype(np.float64).sum())
+            rec[k + "_abs_sum"] = np.float64(np.abs(v.astype(np.float64)).sum())
+            rec[k + "_rows"] = v[:8].copy()
+        else:
+            rec[k] = v
+    np.savez_compressed(os.path.join(HERE, "g6_config1.npz"), **rec)
+
+
+def g8():
+    """Headline codebook shape (K=8192, D=256) on a small batch (N=512): indices, loss,
+    perplexity; inputs regenerated from seeds."""
+    K, D = 8192, 256
+    z = gauss(801, (2, D, 16, 16))
+    E = gauss(802, (K, D))
+    q = make_ref(K, D, 3.0, 0.95, E)
+    q.train(True)
+    o = run_step(q, z, 1.0)
+    st = state_of(q)
+    np.savez_compressed(os.path.join(HERE, "g8_k8192.npz"), z_seed=801, E_seed=802,
+                        indices=o["indices"].astype(np.int16), loss=o["loss"], perplexity=o["perplexity"],
+                        quantized_sum=np.float64(o["quantized"].astype(np.float64).sum()),
+                        state_ema_cluster_size=st["state_ema_cluster_size"],
+                        state_usage_count=st["state_usage_count"],
+                        embedding_sum=np.float64(st["state_embedding_weight"].astype(np.float64).sum()),
+                        embedding_abs_sum=np.float64(np.abs(st["state_embedding_weight"].astype(np.float64)).sum()))
+
+
+if __name__ == "__main__":
+    g1(); g2(); g3(); g4(); g6(); g8()
+    total = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
+    print("golden bytes:", total)

@@ -1,0 +1,150 @@
+"""Pins the CPU oracle (oracle/vq_oracle.c) against golden vectors captured from the
+reference quantizer (tests/golden/make_golden.py).  CPU only."""
+import glob
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, rel_err
+from inputs import gauss
+from oracle import vq_oracle as vo
+
+TOL = 1e-5  # relative to tensor scale; the bar the path's floating-point outputs must meet
+
+
+def classify_mismatches(z, E, idx_a, idx_b, T=1.0):
+    """Rows where two index vectors differ are acceptable only as near-ties: the two
+    candidates' distances, recomputed in float64, differ by no more than a few fp32 ulps
+    of the distance scale ||z||^2 + ||e||^2."""
+    B, D, H, W = z.shape
+    zf = np.transpose(z, (0, 2, 3, 1)).reshape(-1, D).astype(np.float64)
+    bad = np.nonzero(idx_a.ravel() != idx_b.ravel())[0]
+    near = 0
+    for n in bad:
+        ea, eb = E[idx_a.ravel()[n]].astype(np.float64), E[idx_b.ravel()[n]].astype(np.float64)
+        da, db = np.sum((zf[n] - ea) ** 2), np.sum((zf[n] - eb) ** 2)
+        scale = np.sum(zf[n] ** 2) + max(np.sum(ea ** 2), np.sum(eb ** 2))
+        if abs(da - db) <= 8 * np.finfo(np.float32).eps * scale / abs(T):
+            near += 1
+    return len(bad), near
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "g1_*.npz"))))
+def test_single_step(path):
+    g = np.load(path)
+    z = gauss(int(g["z_seed"]), g["quantized"].shape)
+    E = g["E"]
+    st = vo.OracleState.fresh(E)
+    out = vo.forward(z, st, float(g["beta"]), float(g["decay"]), 1e-5, float(g["T"]), bool(g["training"]))
+    nbad, near = classify_mismatches(z, E, out["indices"], g["indices"], float(g["T"]))
+    assert nbad == near, f"{nbad - near} index mismatches that are not near-ties"
+    if nbad == 0:
+        assert rel_err(out["quantized"], g["quantized"]) <= TOL
+        assert abs(out["loss"] - g["loss"]) <= TOL * abs(g["loss"])
+        assert abs(out["perplexity"] - g["perplexity"]) <= TOL * abs(g["perplexity"])
+        assert rel_err(st.embedding, g["state_embedding_weight"]) <= TOL
+        assert rel_err(st.ema_w, g["state_ema_w"]) <= TOL
+        assert rel_err(st.ema_cluster_size, g["state_ema_cluster_size"]) <= TOL
+        assert np.array_equal(st.usage_count, g["state_usage_count"])
+        s = vo.cluster_stats(st.ema_cluster_size, st.usage_count)
+        ref = g["stats"]
+        assert s["active_size"] == int(ref[0])
+        assert abs(s["utilization"] - ref[1]) < 1e-12
+        assert abs(s["entropy"] - ref[2]) <= 1e-5 * max(abs(ref[2]), 1e-3)
+        assert abs(s["normalized_entropy"] - ref[3]) <= 1e-5 * max(abs(ref[3]), 1e-3)
+        assert abs(s["total_usage"] - ref[4]) <= 1e-6 * max(abs(ref[4]), 1.0)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "g2_*.npz"))))
+def test_trajectory(path):
+    """Five training steps: the Laplace-smoothed cluster sizes are stored back each step and
+    codes unused in step 1 collapse to zero rows; both must show up in the oracle's state."""
+    g = np.load(path)
+    st = vo.OracleState.fresh(g["E0"])
+    K, D = g["E0"].shape
+    for step, seed in enumerate(g["z_seeds"]):
+        z = gauss(int(seed), (4, D, 8, 8))
+        E_before = st.embedding.copy()
+        out = vo.forward(z, st, float(g["beta"]), float(g["decay"]), 1e-5, float(g["T"]), True)
+        nbad, near = classify_mismatches(z, E_before, out["indices"], g[f"s{step}_indices"], float(g["T"]))
+        assert nbad == 0, f"step {step}: {nbad} index mismatches ({near} near-ties) - trajectory diverged"
+        assert abs(out["loss"] - g[f"s{step}_loss"]) <= TOL * abs(g[f"s{step}_loss"])
+        assert abs(out["perplexity"] - g[f"s{step}_perplexity"]) <= TOL * abs(g[f"s{step}_perplexity"])
+        assert rel_err(st.ema_cluster_size, g[f"s{step}_state_ema_cluster_size"]) <= TOL
+        assert rel_err(st.ema_w, g[f"s{step}_state_ema_w"]) <= TOL
+        assert rel_err(st.embedding, g[f"s{step}_state_embedding_weight"]) <= TOL
+        assert np.array_equal(st.usage_count, g[f"s{step}_state_usage_count"])
+    unused = g["s0_state_usage_count"] == 0
+    if unused.any():
+        assert np.all(g["s0_state_embedding_weight"][unused] == 0.0)
+        st0 = vo.OracleState.fresh(g["E0"])
+        vo.forward(gauss(int(g["z_seeds"][0]), (4, D, 8, 8)), st0, float(g["beta"]), float(g["decay"]), 1e-5,
+                   float(g["T"]), True)
+        assert np.all(st0.embedding[unused] == 0.0)
+
+
+def test_ties_lowest_index():
+    g = load("g3_ties.npz")
+    idx, _ = vo.search(g["z"], g["E"])
+    assert np.array_equal(idx, g["indices"].ravel())
+    assert idx[0] == 3 and idx[8] == 3          # duplicates of code 3 at rows 5 and 12 never win
+
+
+def test_nonfinite_rows_follow_torch_argmin():
+    g = load("g3_nonfinite.npz")
+    idx, _ = vo.search(g["z"], g["E"])
+    assert np.array_equal(idx, g["indices"].ravel())
+
+
+@pytest.mark.parametrize("name", ["g3_T-1.0.npz", "g3_T0.0.npz"])
+def test_degenerate_temperature(name):
+    g = load(name)
+    idx, _ = vo.search(g["z"], g["E"], T=float(g["T"]))
+    assert np.array_equal(idx, g["indices"].ravel())
+
+
+def test_config1_full():
+    g = load("g6_config1.npz")
+    K, D = 512, 64
+    z = gauss(int(g["z_seed"]), (16, D, 16, 16))
+    E = gauss(int(g["E_seed"]), (K, D)) * np.float32(g["E_scale"])
+    st = vo.OracleState.fresh(E)
+    out = vo.forward(z, st, 3.0, 0.95, 1e-5, 1.0, True)
+    ref_idx = g["indices"].astype(np.int64)
+    assert hashlib.sha256(ref_idx.tobytes()).hexdigest() == str(g["indices_sha256"])
+    nbad, near = classify_mismatches(z, E, out["indices"], ref_idx)
+    assert nbad == near
+    assert nbad == 0
+    assert abs(out["loss"] - g["loss"]) <= TOL * abs(g["loss"])
+    assert abs(out["perplexity"] - g["perplexity"]) <= TOL * abs(g["perplexity"])
+    q64 = out["quantized"].astype(np.float64)
+    assert abs(q64.sum() - g["quantized_sum"]) <= TOL * g["quantized_abs_sum"]
+    assert abs(np.abs(q64).sum() - g["quantized_abs_sum"]) <= TOL * g["quantized_abs_sum"]
+    assert rel_err(st.embedding[:8], g["state_embedding_weight_rows"]) <= TOL
+    assert rel_err(st.ema_w[:8], g["state_ema_w_rows"]) <= TOL
+    assert abs(st.embedding.astype(np.float64).sum() - g["state_embedding_weight_sum"]) <= TOL * g["state_embedding_weight_abs_sum"]
+    assert rel_err(st.ema_cluster_size, g["state_ema_cluster_size"]) <= TOL
+    assert np.array_equal(st.usage_count, g["state_usage_count"])
+
+
+def test_headline_codebook_shape():
+    g = load("g8_k8192.npz")
+    K, D = 8192, 256
+    z = gauss(int(g["z_seed"]), (2, D, 16, 16))
+    E = gauss(int(g["E_seed"]), (K, D))
+    st = vo.OracleState.fresh(E)
+    out = vo.forward(z, st, 3.0, 0.95, 1e-5, 1.0, True)
+    nbad, near = classify_mismatches(z, E, out["indices"], g["indices"].astype(np.int64))
+    assert nbad == near and nbad <= 2
+    if nbad == 0:
+        assert abs(out["loss"] - g["loss"]) <= TOL * abs(g["loss"])
+        assert abs(out["perplexity"] - g["perplexity"]) <= TOL * abs(g["perplexity"])
+        assert rel_err(st.ema_cluster_size, g["state_ema_cluster_size"]) <= TOL
+        assert np.array_equal(st.usage_count, g["state_usage_count"])
+        assert abs(st.embedding.astype(np.float64).sum() - g["embedding_sum"]) <= TOL * g["embedding_abs_sum"]
