@@ -1,0 +1,199 @@
+/*
+ * C ABI of libvqhip.so: the MI355X (gfx950) vector-quantizer hot path.
+ *
+ * Every entry point takes plain device pointers and sizes, enqueues its kernels on the
+ * HIP stream it is given (a hipStream_t passed as void*; NULL = the default stream),
+ * never allocates, never synchronises and never throws.  The return value is a status:
+ * 0 = VQ_OK, VQ_ERR_* for argument errors, VQ_ERR_HIP_BASE + hipError_t for runtime
+ * errors.  All tensors are fp32, indices int64 (plus an int32 working copy), one
+ * caller thread per device.
+ *
+ * "ref:" comments name the lines of the reference (heimaoqqq/VQ-VAE) each entry point
+ * replaces.  A training forward of the reference's EMAVectorQuantizer
+ * (vqvae/ema_vector_quantizer.py:33-108) is, in order:
+ *   vq_codebook_prep -> vq_search -> vq_code_histogram -> vq_ema_scatter ->
+ *   vq_step_scalars -> vq_ema_cluster_update -> vq_ema_codebook_update
+ */
+#ifndef VQ_HIP_H
+#define VQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  VQ_OK = 0,
+  VQ_ERR_INVALID_ARG = 1,   /* null pointer, non-positive size, misaligned buffer          */
+  VQ_ERR_UNSUPPORTED = 2,   /* shape outside what the kernels handle (D > 4096, ...)       */
+  VQ_ERR_HIP_BASE = 1000    /* + hipError_t                                                */
+};
+
+/* Layout of the latent tensor z (and of the quantized output). */
+enum {
+  VQ_LAYOUT_ND = 0,   /* [N][D] row major (ref: vqvae/trainers/vqtrainer.py:60 reshapes to this) */
+  VQ_LAYOUT_NCHW = 1  /* [B][D][HW]; row n = b*HW + hw. Fuses the permute+contiguous of
+                         ref: vqvae/ema_vector_quantizer.py:35-36 and :98 into the loads/stores */
+};
+
+int vq_version(void);
+const char* vq_status_string(int status);
+
+/* ---- sizes of the caller-owned work buffers (bytes; every buffer 256-byte aligned) ---- */
+size_t vq_image_bytes(int K, int D);            /* codebook image, the search's MFMA A operand     */
+size_t vq_norms_bytes(int K);                   /* squared norms of the (padded) codebook          */
+int64_t vq_search_blocks(int64_t N);            /* workgroups of vq_search = loss partials it writes*/
+size_t vq_loss_partial_bytes(int64_t N);        /* floats: vq_search_blocks(N) + fix-up partials   */
+size_t vq_control_bytes(void);                  /* small block of control words                    */
+int vq_scatter_slabs(int64_t N, int K, int D);  /* number of partial-sum slabs vq_ema_scatter writes*/
+
+/*
+ * Codebook preparation.  ref: vqvae/ema_vector_quantizer.py:44 (sum(E**2, dim=1)).
+ * Writes e2[k] = ||E[k]||^2 for k < K (+inf for the padding up to a multiple of 64) and,
+ * when D is one of 16/32/64/128/256, the codebook re-laid out in MFMA-fragment order
+ * ("image").  Sets control word 1 when any norm is NaN or above 1e30 (the search then
+ * takes the exact path for every row).  control must have been zeroed by the caller
+ * (vq_control_reset) before the first kernel of a step.
+ */
+int vq_control_reset(int32_t* control, void* stream);
+int vq_codebook_prep(const float* E, int K, int D, float* image, float* e2, int32_t* control, void* stream);
+
+/*
+ * Nearest-codebook search, fused with gather, straight-through output and the commitment
+ * loss partial sums.  ref: vqvae/ema_vector_quantizer.py:35-58 (distances, temperature,
+ * argmin, one-hot @ E as a gather), :92 (sum((q - z)^2)), :95 (z + (q - z)), :98 (layout).
+ *   z            [N rows], layout as above, D channels; HW only used for NCHW
+ *   E            [K][D] row major codebook (rows code_base .. code_base+K-1 of the full one)
+ *   image, e2    from vq_codebook_prep for the same E
+ *   temperature  distances are divided by it when != 1 (ref :49-50)
+ *   code_base    added to every stored index (codebook-row sharding)
+ *   idx64        [N] int64 out (ref :53), may be NULL
+ *   idx32        [N] int32 out, required (feeds histogram / scatter)
+ *   dmin         [N] winning distance out, may be NULL
+ *   q_out        quantized output in z's layout, may be NULL (then loss_partial unused)
+ *   loss_partial [vq_loss_partial_bytes/4] per-workgroup sums of (q - z)^2, may be NULL
+ *   nf_rows      [N] int32 scratch: rows routed to the exact path (non-finite input)
+ *   control      control words (nf counter, codebook flag)
+ * Ties go to the lowest index; NaN handling follows torch.argmin.
+ */
+int vq_search(const float* z, int layout, int64_t N, int D, int64_t HW, const float* E, const float* image,
+              const float* e2, int K, float temperature, int64_t code_base, int64_t* idx64, int32_t* idx32,
+              float* dmin, float* q_out, float* loss_partial, int32_t* nf_rows, int32_t* control, void* stream);
+
+/* Same search through the exact scalar kernel only (any D <= 4096); used as the in-library
+ * cross-check of the MFMA kernel and for shapes the MFMA kernel does not cover. */
+int vq_search_exact(const float* z, int layout, int64_t N, int D, int64_t HW, const float* E, const float* e2,
+                    int K, float temperature, int64_t code_base, int64_t* idx64, int32_t* idx32, float* dmin,
+                    float* q_out, float* loss_partial, void* stream);
+
+/*
+ * Gather + straight-through + loss partials for given indices (used after a sharded
+ * search has merged its winners).  ref: vqvae/ema_vector_quantizer.py:58, :92, :95, :98.
+ * loss_partial gets vq_search_blocks(N) floats.
+ */
+int vq_gather_st(const float* z, int layout, int64_t N, int D, int64_t HW, const float* E, int K,
+                 const int64_t* idx64, float* q_out, float* loss_partial, void* stream);
+
+/*
+ * Code histogram: counts[k] = #(idx == k).  ref: vqvae/ema_vector_quantizer.py:65
+ * (column sum of the one-hot matrix), vqvae/codebook_utilization_check.py:93-95,
+ * vqvae/vqgan_trainer.py:601-603.  idx is int32 when idx_is_64 == 0, else int64.
+ * counts is zeroed first unless accumulate != 0.  Out-of-range indices are counted in
+ * control word 2 and otherwise ignored.
+ */
+int vq_code_histogram(const void* idx, int idx_is_64, int64_t M, int K, uint32_t* counts, int accumulate,
+                      int32_t* control, void* stream);
+
+/*
+ * EMA embedding sums: slab[s][k][c] = sum of z[n][c] over the rows n of slab s with
+ * idx32[n] == k.  ref: vqvae/ema_vector_quantizer.py:84 (encodings.t() @ flat_input).
+ * Writes vq_scatter_slabs(N,K,D) slabs of K*D floats; their sum over s is dw.  LDS-private
+ * accumulation, one wave per channel, so the result is reproducible run to run.
+ */
+int vq_ema_scatter(const float* z, int layout, int64_t N, int D, int64_t HW, const int32_t* idx32, int K,
+                   float* slabs, void* stream);
+
+/* dw[k][c] = sum_s slabs[s][k][c] in slab order (packs the data-parallel all-reduce buffer). */
+int vq_reduce_slabs(const float* slabs, int nslab, int K, int D, float* dw, void* stream);
+
+/*
+ * Scalars of one forward.  ref: vqvae/ema_vector_quantizer.py:92 (loss = beta * mean) and
+ * :105-106 (perplexity = exp(-sum p ln(p + 1e-10)), p = counts / N_total).
+ * sq_sum_out (may be NULL) receives the plain sum of squares, for data-parallel reduction.
+ */
+int vq_step_scalars(const float* loss_partial, int64_t n_partial, int64_t N_total, int D, float beta,
+                    const uint32_t* counts, int K, float* loss_out, float* perplexity_out, double* sq_sum_out,
+                    void* stream);
+
+/*
+ * EMA cluster-size update with the persisted Laplace smoothing.
+ * ref: vqvae/ema_vector_quantizer.py:67 (usage_count += counts), :71-72, :75-80.
+ * decay, one_minus_decay, eps, k_eps are the reference's Python-double expressions
+ * (decay, 1 - decay, epsilon, K * epsilon) rounded to fp32 by the caller.
+ * counts64 (may be NULL) overrides counts with int64 values (all-reduced counts).
+ */
+int vq_ema_cluster_update(const uint32_t* counts, const int64_t* counts64, int K, float decay,
+                          float one_minus_decay, float eps, float k_eps, float* usage, float* cluster_size,
+                          void* stream);
+
+/*
+ * EMA embedding update and renormalisation.  ref: vqvae/ema_vector_quantizer.py:85, :89.
+ * ema_w = ema_w*decay + (1-decay)*sum_s slabs[s]; E = ema_w / cluster_size[:, None].
+ */
+int vq_ema_codebook_update(const float* slabs, int nslab, int K, int D, float decay, float one_minus_decay,
+                           const float* cluster_size, float* ema_w, float* E, void* stream);
+
+/*
+ * Backward of the forward's differentiable part.  ref: autograd of
+ * vqvae/ema_vector_quantizer.py:92 and :95:
+ *   grad_z = grad_q + grad_loss * coef * (z - q_st),  coef = 2*beta/(N*D)
+ * grad_q may be NULL (treated as zero); grad_loss is a device scalar (NULL = 0).
+ */
+int vq_backward(const float* grad_q, const float* grad_loss, const float* z, const float* q_st, int64_t numel,
+                float coef, float* grad_z, void* stream);
+
+/* One-hot matrix enc[N][K] (fp32).  ref: vqvae/ema_vector_quantizer.py:54-55. */
+int vq_onehot(const int64_t* idx64, int64_t N, int K, float* enc, void* stream);
+
+/*
+ * get_codebook_stats.  ref: vqvae/ema_vector_quantizer.py:205-232.
+ * out[5] (double, device): active count, utilisation, entropy (log2), normalised entropy,
+ * total usage.
+ */
+int vq_cluster_stats(const float* cluster_size, const float* usage, int K, double* out, void* stream);
+
+/*
+ * Index statistics from a histogram.  out64[5]: ref vqvae/codebook_utilization_check.py:86-108
+ * (#unique, utilisation, entropy, normalised entropy, the "gini" of :108), float64 like
+ * NumPy.  out32[4]: ref vqvae/vqgan_trainer.py:594-612 (#unique, utilisation, entropy,
+ * normalised entropy), fp32 like the torch code.  Either may be NULL.
+ */
+int vq_index_stats(const uint32_t* counts, int K, int64_t M, double* out64, float* out32, void* stream);
+
+/*
+ * Pairwise codebook distances (the analysis ref README.md:26-29 describes; the reference
+ * holds no code for it).  nn_dist[i] / nn_idx[i]: nearest other code of i; out[3] (double):
+ * min, mean, max over ordered pairs i != j (NaN when the codebook holds non-finite rows).
+ * sum_partial: vq_search_blocks(K) doubles of scratch; mm_partial: 2*vq_search_blocks(K) + K
+ * 4-byte words of scratch.
+ */
+int vq_pairwise_stats(const float* E, const float* image, const float* e2, int K, int D, float* nn_dist,
+                      int64_t* nn_idx, double* sum_partial, float* mm_partial, double* out, int32_t* control,
+                      void* stream);
+
+/*
+ * Codebook-row-sharded search support: pack (distance, index) into one uint64 whose
+ * unsigned order is the order torch.argmin would see on the unsharded distance matrix
+ * (NaN first, then ascending distance, then ascending index), and unpack the winner after
+ * an all-reduce(MIN).  ref: vqvae/ema_vector_quantizer.py:53 applied across shards.
+ */
+int vq_pack_dist_index(const float* dmin, const int64_t* idx64, int64_t N, uint64_t* packed, void* stream);
+int vq_unpack_dist_index(const uint64_t* packed, int64_t N, float* dmin, int64_t* idx64, int32_t* idx32,
+                         void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQ_HIP_H */

@@ -1,0 +1,258 @@
+"""GPU parity: HIP kernels (through the C ABI) against the CPU oracle and the golden vectors.
+
+Bars: indices, histograms and everything integer are bit-exact; with equal indices the
+straight-through output and the winning distances are bit-exact too (same fp32 operation
+order); sums (loss, EMA statistics, codebook) within 1e-5 of the tensor's scale.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, rel_err
+from inputs import gauss, ref_init_codebook
+from oracle import vq_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from vq_vae_amd import ops as _ops
+    return _ops
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+CASES = [
+    # (K, D, z shape) -- NCHW unless 2-D
+    (512, 64, (16, 64, 16, 16)),        # BASELINE config 1
+    (8192, 256, (2, 256, 32, 32)),      # headline codebook shape, 2048 rows
+    (64, 256, (1, 256, 8, 8)),          # improved_vq_config: K=64
+    (100, 32, (3, 32, 5, 7)),           # K not a multiple of 64, HW=35 unaligned, rows % 256 != 0
+    (640, 128, (1, 128, 1, 1)),         # a single row
+    (8192, 256, (300, 256)),            # row-major latents
+    (200, 16, (1000, 16)),
+]
+
+
+@pytest.mark.parametrize("K,D,shape", CASES)
+def test_search_bit_exact(K, D, shape, dev, ops):
+    z = gauss(11, shape)
+    E = gauss(12, (K, D)) * np.float32(0.8)
+    ws = ops.Workspace(dev)
+    zt, Et = _t(z, dev), _t(E, dev)
+    image, e2, control = ops.prepare_codebook(Et, ws)
+    assert np.array_equal(_bits(e2[:K].cpu().numpy()), _bits(vo.codebook_norms(E))), "codebook norms differ"
+    assert torch.isinf(e2[K:]).all()
+    r = ops.search(zt, Et, ws, want_quantized=True, want_dmin=True, prepared=(image, e2, control))
+    torch.cuda.synchronize()
+    idx_o, dmin_o = vo.search(z, E)
+    idx_g = r["indices"].cpu().numpy()
+    assert np.array_equal(idx_g, idx_o), f"{np.count_nonzero(idx_g != idx_o)} of {idx_o.size} indices differ"
+    assert np.array_equal(r["idx32"][: idx_o.size].cpu().numpy(), idx_o.astype(np.int32))
+    assert np.array_equal(_bits(r["dmin"].cpu().numpy()), _bits(dmin_o)), "winning distances differ"
+    q_o, sq_o = vo.gather_st(z, E, idx_o)
+    assert np.array_equal(_bits(r["quantized"].cpu().numpy()), _bits(q_o)), "straight-through output differs"
+    sq_g = float(r["loss_partial"][: r["n_partial"]].double().sum().item())
+    assert abs(sq_g - sq_o) <= TOL * sq_o
+    # the exact scalar kernel must agree with the MFMA kernel bit for bit
+    rx = ops.search(zt, Et, ws, want_quantized=True, want_dmin=True, exact=True, prepared=(image, e2, control))
+    assert torch.equal(rx["indices"], r["indices"])
+    assert torch.equal(rx["dmin"].view(torch.int32), r["dmin"].view(torch.int32))
+    assert torch.equal(rx["quantized"].view(torch.int32), r["quantized"].view(torch.int32))
+
+
+@pytest.mark.parametrize("T", [2.5, 0.7])
+def test_search_temperature(T, dev, ops):
+    K, D = 512, 64
+    z = gauss(21, (4, D, 8, 8))
+    E = gauss(22, (K, D)) * np.float32(0.5)
+    ws = ops.Workspace(dev)
+    r = ops.search(_t(z, dev), _t(E, dev), ws, temperature=T, want_dmin=True)
+    idx_o, dmin_o = vo.search(z, E, T=T)
+    assert np.array_equal(r["indices"].cpu().numpy(), idx_o)
+    assert np.array_equal(_bits(r["dmin"].cpu().numpy()), _bits(dmin_o))
+
+
+def test_ties_and_duplicates(dev, ops):
+    g = np.load(os.path.join(GOLDEN, "g3_ties.npz"))
+    # D=8 is not an MFMA shape: widen to 16 channels with zeros (distances unchanged)
+    E = np.zeros((16, 16), np.float32); E[:, :8] = g["E"]
+    z = np.zeros((1, 16, 4, 4), np.float32); z[:, :8] = g["z"]
+    ws = ops.Workspace(dev)
+    r = ops.search(_t(z, dev), _t(E, dev), ws)
+    assert np.array_equal(r["indices"].cpu().numpy(), g["indices"].ravel())
+    # native D=8 goes through the exact kernel
+    r8 = ops.search(_t(g["z"], dev), _t(g["E"], dev), ws)
+    assert np.array_equal(r8["indices"].cpu().numpy(), g["indices"].ravel())
+
+
+def test_nonfinite_rows_follow_torch_argmin(dev, ops):
+    g = np.load(os.path.join(GOLDEN, "g3_nonfinite.npz"))
+    ws = ops.Workspace(dev)
+    r8 = ops.search(_t(g["z"], dev), _t(g["E"], dev), ws)
+    assert np.array_equal(r8["indices"].cpu().numpy(), g["indices"].ravel())
+    # the same rows inside an MFMA-shaped problem: flagged rows take the exact path
+    K, D = 512, 64
+    z = gauss(31, (2, D, 16, 16))
+    E = gauss(32, (K, D))
+    z[0, 3, 0, 0] = np.nan
+    z[0, 5, 0, 1] = np.inf
+    z[1, 7, 2, 2] = -np.inf
+    z[1, :, 3, 3] = 3e19            # squared norm overflows
+    r = ops.search(_t(z, dev), _t(E, dev), ws, want_dmin=True)
+    idx_o, dmin_o = vo.search(z, E)
+    assert np.array_equal(r["indices"].cpu().numpy(), idx_o)
+    assert np.array_equal(_bits(r["dmin"].cpu().numpy()), _bits(dmin_o))
+    q_o, _ = vo.gather_st(z, E, idx_o)
+    assert np.array_equal(_bits(r["quantized"].cpu().numpy()), _bits(q_o))
+    # a codebook with a non-finite row
+    E2 = E.copy(); E2[77, 3] = np.nan
+    r = ops.search(_t(z, dev), _t(E2, dev), ws)
+    idx_o, _ = vo.search(z, E2)
+    assert np.array_equal(r["indices"].cpu().numpy(), idx_o)
+    # the NaN column wins every row whose own distances are not all NaN, as in torch.argmin
+    assert (idx_o == 77).sum() >= idx_o.size - 4 and set(np.unique(idx_o)) <= {0, 77}
+
+
+@pytest.mark.parametrize("name", ["g3_T-1.0.npz", "g3_T0.0.npz"])
+def test_degenerate_temperature(name, dev, ops):
+    g = np.load(os.path.join(GOLDEN, name))
+    E = np.zeros((16, 16), np.float32); E[:, :8] = g["E"]
+    z = np.zeros((1, 16, 4, 4), np.float32); z[:, :8] = g["z"]
+    ws = ops.Workspace(dev)
+    r = ops.search(_t(z, dev), _t(E, dev), ws, temperature=float(g["T"]))
+    assert np.array_equal(r["indices"].cpu().numpy(), g["indices"].ravel())
+
+
+@pytest.mark.parametrize("K,D,shape", [(512, 64, (16, 64, 16, 16)), (8192, 256, (4, 256, 32, 32)),
+                                       (100, 32, (3, 32, 5, 7)), (300, 24, (2, 24, 9, 9))])
+def test_histogram_and_embed_sums(K, D, shape, dev, ops):
+    z = gauss(41, shape)
+    rng = np.random.Generator(np.random.PCG64(42))
+    N = z.size // D
+    idx = rng.integers(0, K, N, dtype=np.int64)
+    idx[: N // 3] = idx[0]                                # a heavy code
+    ws = ops.Workspace(dev)
+    counts = ops.histogram(_t(idx, dev), K, ws)
+    assert np.array_equal(counts.cpu().numpy().view(np.uint32).astype(np.int64), vo.histogram(idx, K))
+    counts32 = ops.histogram(_t(idx.astype(np.int32), dev), K, ws)
+    assert torch.equal(counts, counts32)
+    slabs, nslab = ops.embed_sums(_t(z, dev), _t(idx.astype(np.int32), dev), K, ws)
+    dw = ops.reduce_slabs(slabs).cpu().numpy()
+    assert rel_err(dw, vo.embed_sum(z, idx, K)) <= TOL
+    # reproducible: a second run gives the same bits
+    slabs2, _ = ops.embed_sums(_t(z, dev), _t(idx.astype(np.int32), dev), K, ws)
+    assert np.array_equal(_bits(ops.reduce_slabs(slabs2).cpu().numpy()), _bits(dw))
+
+
+def _gpu_state(E, dev):
+    K, D = E.shape
+    return {"E": _t(E, dev), "ema_w": torch.zeros(K, D, device=dev), "cs": torch.zeros(K, device=dev),
+            "usage": torch.zeros(K, device=dev)}
+
+
+def _check_step(out, o_ref, st_gpu, st_ref):
+    assert np.array_equal(out.indices.cpu().numpy(), o_ref["indices"].ravel())
+    assert np.array_equal(_bits(out.quantized.cpu().numpy()), _bits(o_ref["quantized"]))
+    assert abs(out.loss.item() - o_ref["loss"]) <= TOL * abs(o_ref["loss"])
+    assert abs(out.perplexity.item() - o_ref["perplexity"]) <= TOL * abs(o_ref["perplexity"])
+    assert np.array_equal(st_gpu["usage"].cpu().numpy(), st_ref.usage_count)
+    assert rel_err(st_gpu["cs"].cpu().numpy(), st_ref.ema_cluster_size) <= TOL
+    assert rel_err(st_gpu["ema_w"].cpu().numpy(), st_ref.ema_w) <= TOL
+    assert rel_err(st_gpu["E"].cpu().numpy(), st_ref.embedding) <= TOL
+
+
+@pytest.mark.parametrize("K,D,shape,decay,beta,T", [
+    (512, 64, (16, 64, 16, 16), 0.95, 3.0, 1.0),
+    (64, 256, (2, 256, 16, 16), 0.7, 10.0, 2.5),
+    (8192, 256, (8, 256, 32, 32), 0.95, 3.0, 1.0),
+])
+def test_training_trajectory(K, D, shape, decay, beta, T, dev, ops):
+    """Several training steps.  Each step the oracle restarts from the GPU's own state, so the
+    index comparison stays bit-exact while the float state is compared with the tolerance; a
+    free-running oracle is compared at the end."""
+    E0 = gauss(52, (K, D)) * np.float32(0.7)
+    ws = ops.Workspace(dev)
+    g = _gpu_state(E0, dev)
+    free = vo.OracleState.fresh(E0)
+    for step in range(4):
+        z = gauss(60 + step, shape)
+        synced = vo.OracleState(g["E"].cpu().numpy().copy(), g["cs"].cpu().numpy().copy(),
+                                g["ema_w"].cpu().numpy().copy(), g["usage"].cpu().numpy().copy())
+        o_ref = vo.forward(z, synced, beta, decay, 1e-5, T, True)
+        vo.forward(z, free, beta, decay, 1e-5, T, True)
+        out = ops.quantize_step(_t(z, dev), g["E"], g["ema_w"], g["cs"], g["usage"], beta=beta, decay=decay,
+                                epsilon=1e-5, temperature=T, training=True, ws=ws)
+        torch.cuda.synchronize()
+        _check_step(out, o_ref, g, synced)
+    assert rel_err(g["E"].cpu().numpy(), free.embedding) <= 1e-4
+    assert rel_err(g["cs"].cpu().numpy(), free.ema_cluster_size) <= 1e-4
+
+
+def test_eval_step_leaves_state_alone(dev, ops):
+    K, D = 512, 64
+    E0 = gauss(72, (K, D)) * np.float32(0.5)
+    z = gauss(71, (4, D, 16, 16))
+    ws = ops.Workspace(dev)
+    g = _gpu_state(E0, dev)
+    out = ops.quantize_step(_t(z, dev), g["E"], g["ema_w"], g["cs"], g["usage"], beta=3.0, decay=0.95, epsilon=1e-5,
+                            temperature=1.0, training=False, ws=ws)
+    st = vo.OracleState.fresh(E0)
+    o_ref = vo.forward(z, st, 3.0, 0.95, 1e-5, 1.0, False)
+    _check_step(out, o_ref, g, st)
+    assert np.array_equal(g["E"].cpu().numpy(), E0)
+
+
+def test_golden_config1_on_gpu(dev, ops):
+    """BASELINE config 1 against the reference's own outputs (golden vector g6)."""
+    g = np.load(os.path.join(GOLDEN, "g6_config1.npz"))
+    K, D = 512, 64
+    z = gauss(int(g["z_seed"]), (16, D, 16, 16))
+    E = gauss(int(g["E_seed"]), (K, D)) * np.float32(g["E_scale"])
+    ws = ops.Workspace(dev)
+    st = _gpu_state(E, dev)
+    out = ops.quantize_step(_t(z, dev), st["E"], st["ema_w"], st["cs"], st["usage"], beta=3.0, decay=0.95,
+                            epsilon=1e-5, temperature=1.0, training=True, ws=ws)
+    ref_idx = g["indices"].astype(np.int64).ravel()
+    assert np.array_equal(out.indices.cpu().numpy(), ref_idx)
+    assert abs(out.loss.item() - g["loss"]) <= TOL * abs(g["loss"])
+    assert abs(out.perplexity.item() - g["perplexity"]) <= TOL * abs(g["perplexity"])
+    q64 = out.quantized.double().cpu().numpy()
+    assert abs(q64.sum() - g["quantized_sum"]) <= TOL * g["quantized_abs_sum"]
+    assert rel_err(st["E"][:8].cpu().numpy(), g["state_embedding_weight_rows"]) <= TOL
+    assert rel_err(st["ema_w"][:8].cpu().numpy(), g["state_ema_w_rows"]) <= TOL
+    assert rel_err(st["cs"].cpu().numpy(), g["state_ema_cluster_size"]) <= TOL
+    assert np.array_equal(st["usage"].cpu().numpy(), g["state_usage_count"])
+
+
+def test_reference_init_collapse(dev, ops):
+    """The reference's U(-1/K, 1/K) initialisation against N(0,1) latents: nearly every row picks
+    the same few codes; after one step every unused code becomes the zero vector."""
+    g = np.load(os.path.join(GOLDEN, "g1_refinit_train_T1.0.npz"))
+    z = gauss(int(g["z_seed"]), g["quantized"].shape)
+    E = g["E"]
+    ws = ops.Workspace(dev)
+    st = _gpu_state(E, dev)
+    out = ops.quantize_step(_t(z, dev), st["E"], st["ema_w"], st["cs"], st["usage"], beta=float(g["beta"]),
+                            decay=float(g["decay"]), epsilon=1e-5, temperature=1.0, training=True, ws=ws)
+    assert np.array_equal(out.indices.cpu().numpy(), g["indices"].ravel())
+    assert rel_err(st["E"].cpu().numpy(), g["state_embedding_weight"]) <= TOL
+    unused = g["state_usage_count"] == 0
+    assert (st["E"].cpu().numpy()[unused] == 0).all()

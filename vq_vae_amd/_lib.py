@@ -1,0 +1,83 @@
+"""ctypes binding of libvqhip.so (include/vq_hip.h).
+
+The library is the product: there is no fallback.  Loading fails loudly when the shared
+object is missing, and every call checks the returned status.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libvqhip.so")
+
+LAYOUT_ND, LAYOUT_NCHW = 0, 1
+
+#: every symbol include/vq_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "vq_version": (c_int, []),
+    "vq_status_string": (ctypes.c_char_p, [c_int]),
+    "vq_image_bytes": (c_size_t, [c_int, c_int]),
+    "vq_norms_bytes": (c_size_t, [c_int]),
+    "vq_search_blocks": (c_int64, [c_int64]),
+    "vq_loss_partial_bytes": (c_size_t, [c_int64]),
+    "vq_control_bytes": (c_size_t, []),
+    "vq_scatter_slabs": (c_int, [c_int64, c_int, c_int]),
+    "vq_control_reset": (c_int, [c_void_p, c_void_p]),
+    "vq_codebook_prep": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vq_search": (c_int, [c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_float,
+                          c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vq_search_exact": (c_int, [c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_void_p, c_int, c_float, c_int64,
+                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vq_gather_st": (c_int, [c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                             c_void_p]),
+    "vq_code_histogram": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "vq_ema_scatter": (c_int, [c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
+    "vq_reduce_slabs": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vq_step_scalars": (c_int, [c_void_p, c_int64, c_int64, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p,
+                                c_void_p, c_void_p]),
+    "vq_ema_cluster_update": (c_int, [c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_void_p,
+                                      c_void_p, c_void_p]),
+    "vq_ema_codebook_update": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p,
+                                       c_void_p]),
+    "vq_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p]),
+    "vq_onehot": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "vq_cluster_stats": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "vq_index_stats": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
+    "vq_pairwise_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p]),
+    "vq_pack_dist_index": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "vq_unpack_dist_index": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+}
+
+
+class VQLibraryError(RuntimeError):
+    """A libvqhip.so entry point returned a non-zero status."""
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libvqhip.so and attach the signatures.  Raises when the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m vq_vae_amd.build` (hipcc, gfx950). "
+            "The quantizer has no CPU or PyTorch fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = the .so and the header disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load().vq_status_string(status).decode()
+        raise VQLibraryError(f"{what} failed: status {status} ({msg})")

@@ -1,0 +1,757 @@
+// Nearest-codebook search for gfx950 (MI355X).
+//
+// Replaces vqvae/ema_vector_quantizer.py:35-58, :92-98 of the reference: distances
+// ||z||^2 + ||e||^2 - 2 z.e, optional temperature, argmin with lowest-index ties, the
+// gather of the winning code, the straight-through output and the commitment-loss sum.
+// The N x K distance matrix and the N x K one-hot matrix never exist in memory.
+//
+// Design (z-stationary, MFMA-bound):
+//   * A workgroup of 4 waves owns 256 rows of z.  Each wave keeps its 64 rows (two 32-row
+//     MFMA column tiles) in registers for the whole sweep -- the 512 KiB register file of
+//     a CU is the largest on-chip store, so z is read from HBM exactly once and never
+//     touches LDS.
+//   * The codebook streams through LDS in stages of 64 codes.  vq_codebook_prep stores it
+//     in "image" order, i.e. exactly the bytes a wave's lanes want for the A operand of
+//     v_mfma_f32_32x32x2_f32, so a stage is a linear 65 KiB global->LDS DMA copy
+//     (global_load_lds_dwordx4) and an A fragment for four k-steps is one conflict-free
+//     ds_read_b128 per lane.  Two stage buffers: the DMA of stage s+1 flies under the
+//     MFMAs of stage s.
+//   * MFMA orientation: codes on the 32 rows (A), latents on the 32 columns (B).  A lane
+//     then holds 16 distances of ONE latent, so the argmin is a register scan plus one
+//     cross-half exchange at the very end.
+//   * fp32 MFMA is bit-for-bit an fmaf chain over the channels in increasing order, which
+//     is what the CPU oracle computes; indices are therefore compared bit-exactly.
+//   * The scan of a finished 32x64 accumulator pair runs while the MFMAs of the next pair
+//     are in flight (two accumulator sets alternate).
+#include "vq_common.h"
+
+namespace {
+
+struct SearchArgs {
+  const float* z;
+  const float* E;       // row-major codebook, for the gather
+  const float* image;   // staged codebook
+  const float* e2;      // per-code squared norms (exact kernel)
+  int64_t N;
+  int64_t HW;
+  int K;
+  int nstages;
+  float T;
+  int64_t code_base;
+  int64_t* idx64;
+  int32_t* idx32;
+  float* dmin;
+  float* q_out;
+  float* loss_partial;
+  int32_t* nf_rows;
+  int32_t* control;
+  // pairwise mode (z := E): skip the pair (n, n); per-workgroup partials of sum/min/max
+  double* pw_sum;
+  float* pw_minmax;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// Issue the LDS-DMA copy of one codebook stage.  The image is lane-linear, so piece p of
+// the stage (1 KiB) goes to LDS offset p*1024; lane l supplies bytes [16l, 16l+16).
+template <int D>
+__device__ __forceinline__ void stage_copy(const float* image, int stage, float* lds_buf, int wave, int lane) {
+  constexpr int PIECES = D / 4 + 1;
+  const char* src = reinterpret_cast<const char*>(image) + (size_t)stage * vq_stage_floats(D) * 4 + lane * 16;
+  char* dst = reinterpret_cast<char*>(lds_buf);
+#pragma unroll
+  for (int i = 0; i < (PIECES + 3) / 4; ++i) {
+    const int p = i * 4 + wave;
+    if (p < PIECES) {
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(src + (size_t)p * 1024),
+          (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
+    }
+  }
+}
+
+// Scan one finished 32-code x 32-latent accumulator tile.  Register r of the tile is code
+// row (r&3) + 8*(r>>2) + 4*(lane>>5); the 4*(lane>>5) part is added once after the sweep.
+template <bool TEMP, bool PAIRWISE>
+__device__ __forceinline__ void scan_tile(const f32x16& c, const f32x4 (&e2v)[4], float z2, int code0, float T,
+                                          int self_code, float& best, int& bidx, double& psum, float& pmin,
+                                          float& pmax) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float t = z2 + e2v[q][r];
+      float d = __builtin_fmaf(-2.0f, c[4 * q + r], t);
+      if (TEMP) d = d / T;
+      const int code = code0 + 8 * q + r;
+      if (PAIRWISE) {
+        const bool real = (e2v[q][r] < __builtin_inff()) && (code != self_code);
+        if (real) {
+          psum += (double)d;
+          pmin = d < pmin ? d : pmin;
+          pmax = d > pmax ? d : pmax;
+        } else {
+          d = __builtin_inff();
+        }
+      }
+      const bool tk = d < best;
+      best = tk ? d : best;
+      bidx = tk ? code : bidx;
+    }
+  }
+}
+
+template <int D, bool NCHW, bool TEMP, bool PAIRWISE>
+__global__ __launch_bounds__(256, 1) void vq_search_mfma_kernel(SearchArgs a) {
+  constexpr int S = D / 2;  // k-steps of the 32x32x2 MFMA
+  constexpr int G = D / 8;  // ds_read_b128 groups (4 k-steps each)
+  constexpr int STAGE_F = VQ_STAGE_CODES * D + 256;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int64_t row0 = (int64_t)blockIdx.x * VQ_WG_ROWS + wave * 64;
+
+  // A non-finite codebook sends every row to the exact kernel.
+  if (a.control[VQ_CTL_CB_FLAG] != 0) {
+    if (threadIdx.x == 0 && a.loss_partial) a.loss_partial[blockIdx.x] = 0.0f;
+    if (h == 0) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const int64_t n = row0 + ct * 32 + j;
+        if (n < a.N) a.nf_rows[atomicAdd(&a.control[VQ_CTL_NF_COUNT], 1)] = (int32_t)n;
+      }
+    }
+    return;
+  }
+
+  // Prologue DMA of stage 0 goes out first; it lands while z is being loaded.
+  stage_copy<D>(a.image, 0, lds, wave, lane);
+
+  // ---- z tile into registers, in B-operand order: zr[ct][s] = z[row][2s + h] -----------
+  float zr[2][S];
+  float z2[2];
+  int64_t zoff[2];            // element offset of this lane's first channel of the row
+  int64_t zstride = 2 * a.HW;  // NCHW: elements between channels 2s+h and 2s+2+h
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    int64_t n = row0 + ct * 32 + j;
+    if (n >= a.N) n = a.N - 1;  // clamped duplicate: loads stay in bounds, outputs are masked
+    float p = 0.0f;
+    if (NCHW) {
+      const int64_t b = n / a.HW, hw = n - b * a.HW;
+      zoff[ct] = (b * D + h) * a.HW + hw;
+      const float* src = a.z + zoff[ct];
+#pragma unroll
+      for (int s = 0; s < S; ++s) zr[ct][s] = src[(int64_t)s * zstride];
+    } else {
+      zoff[ct] = n * D;
+      const f32x4* src = reinterpret_cast<const f32x4*>(a.z + zoff[ct]);
+#pragma unroll
+      for (int m = 0; m < D / 4; ++m) {
+        const f32x4 v = src[m];
+        zr[ct][2 * m] = h ? v[1] : v[0];
+        zr[ct][2 * m + 1] = h ? v[3] : v[2];
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) p = __builtin_fmaf(zr[ct][s], zr[ct][s], p);
+    z2[ct] = p + __shfl_xor(p, 32);  // even-channel chain + odd-channel chain
+    // Cut the address expressions of the loads off from those of the stores after the
+    // sweep: otherwise the compiler keeps 128 store addresses alive through the MFMA loop.
+    asm volatile("" : "+v"(zoff[ct]));
+  }
+  asm volatile("" : "+s"(zstride));
+
+  float best[2] = {__builtin_inff(), __builtin_inff()};
+  int bidx[2] = {0, 0};
+  double psum[2] = {0.0, 0.0};
+  float pmin[2] = {__builtin_inff(), __builtin_inff()};
+  float pmax[2] = {-__builtin_inff(), -__builtin_inff()};
+  int self_code[2] = {-1, -1};
+  if (PAIRWISE) {
+    // the row index is the code index; remove the 4*h part the scan leaves out
+    self_code[0] = (int)(row0 + j) - 4 * h;
+    self_code[1] = (int)(row0 + 32 + j) - 4 * h;
+  }
+
+  // Accumulator set B (second 32 codes of a stage) is scanned one stage late, under the
+  // MFMAs of the next stage's first half.  Before the first stage it holds zeros and its
+  // norms are +inf, so that first scan changes nothing.
+  f32x16 cB0, cB1;
+  f32x4 e2B[4];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { cB0[i] = 0.0f; cB1[i] = 0.0f; }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) e2B[q] = f32x4{__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()};
+
+  __syncthreads();  // stage 0 has landed (the barrier waits for this wave's DMA first)
+
+  int cur = 0;
+  for (int st = 0; st < a.nstages; ++st) {
+    float* buf = lds + cur * STAGE_F;
+    if (st + 1 < a.nstages) stage_copy<D>(a.image, st + 1, lds + (cur ^ 1) * STAGE_F, wave, lane);
+
+    const f32x4* A = reinterpret_cast<const f32x4*>(buf) + lane;
+    const f32x4* e2s = reinterpret_cast<const f32x4*>(buf + VQ_STAGE_CODES * D) + h;
+
+    // ---- first half: codes [64 st, 64 st + 32) into set A; scan set B of stage st-1 -----
+    f32x16 cA0, cA1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { cA0[i] = 0.0f; cA1[i] = 0.0f; }
+    {
+      f32x4 af = A[0];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const f32x4 an = A[(g + 1 < G ? g + 1 : g) * 64];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          cA0 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], zr[0][4 * g + q], cA0, 0, 0, 0);
+          cA1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], zr[1][4 * g + q], cA1, 0, 0, 0);
+        }
+        af = an;
+      }
+    }
+    {
+      const int code0 = (st - 1) * VQ_STAGE_CODES + 32;
+      scan_tile<TEMP, PAIRWISE>(cB0, e2B, z2[0], code0, a.T, self_code[0], best[0], bidx[0], psum[0], pmin[0], pmax[0]);
+      scan_tile<TEMP, PAIRWISE>(cB1, e2B, z2[1], code0, a.T, self_code[1], best[1], bidx[1], psum[1], pmin[1], pmax[1]);
+    }
+
+    // ---- second half: codes [64 st + 32, 64 st + 64) into set B; scan set A --------------
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { cB0[i] = 0.0f; cB1[i] = 0.0f; }
+    {
+      f32x4 af = A[G * 64];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const f32x4 an = A[(G + (g + 1 < G ? g + 1 : g)) * 64];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          cB0 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], zr[0][4 * g + q], cB0, 0, 0, 0);
+          cB1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], zr[1][4 * g + q], cB1, 0, 0, 0);
+        }
+        af = an;
+      }
+    }
+    {
+      f32x4 e2A[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) e2A[q] = e2s[2 * q];
+      const int code0 = st * VQ_STAGE_CODES;
+      scan_tile<TEMP, PAIRWISE>(cA0, e2A, z2[0], code0, a.T, self_code[0], best[0], bidx[0], psum[0], pmin[0], pmax[0]);
+      scan_tile<TEMP, PAIRWISE>(cA1, e2A, z2[1], code0, a.T, self_code[1], best[1], bidx[1], psum[1], pmin[1], pmax[1]);
+    }
+    // norms of this stage's second half, kept for the deferred scan
+#pragma unroll
+    for (int q = 0; q < 4; ++q) e2B[q] = e2s[8 + 2 * q];
+
+    __syncthreads();  // every wave is done with buf; the DMA of stage st+1 has landed
+    cur ^= 1;
+  }
+  {
+    const int code0 = (a.nstages - 1) * VQ_STAGE_CODES + 32;
+    scan_tile<TEMP, PAIRWISE>(cB0, e2B, z2[0], code0, a.T, self_code[0], best[0], bidx[0], psum[0], pmin[0], pmax[0]);
+    scan_tile<TEMP, PAIRWISE>(cB1, e2B, z2[1], code0, a.T, self_code[1], best[1], bidx[1], psum[1], pmin[1], pmax[1]);
+  }
+
+  // ---- merge the two lane halves (rows +0..3 vs +4..7 of every 8), write the winners ----
+  float lp = 0.0f;
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    int bi = bidx[ct] + 4 * h;
+    float b = best[ct];
+    const float ob = __shfl_xor(b, 32);
+    const int oi = __shfl_xor(bi, 32);
+    const bool take = (ob < b) || (ob == b && oi < bi);
+    b = take ? ob : b;
+    bi = take ? oi : bi;
+
+    const int64_t n = row0 + ct * 32 + j;
+    const bool valid = n < a.N;
+    const bool finite = z2[ct] <= VQ_NORM_LIMIT;  // false for NaN
+    const bool ok = valid && finite;
+    if (h == 0) {
+      if (ok) {
+        if (a.idx64) a.idx64[n] = (int64_t)bi + a.code_base;
+        if (a.idx32) a.idx32[n] = (int32_t)(bi + a.code_base);
+        if (a.dmin) a.dmin[n] = b;
+      } else if (valid) {
+        a.nf_rows[atomicAdd(&a.control[VQ_CTL_NF_COUNT], 1)] = (int32_t)n;
+      }
+    }
+    if (PAIRWISE) {
+      // reduce sum/min/max of this latent's distances over the two halves
+      psum[ct] += __shfl_xor(psum[ct], 32);
+      const float omn = __shfl_xor(pmin[ct], 32), omx = __shfl_xor(pmax[ct], 32);
+      pmin[ct] = omn < pmin[ct] ? omn : pmin[ct];
+      pmax[ct] = omx > pmax[ct] ? omx : pmax[ct];
+      if (!valid || h != 0) { psum[ct] = 0.0; pmin[ct] = __builtin_inff(); pmax[ct] = -__builtin_inff(); }
+    }
+
+    // ---- gather E[bi], straight-through output, squared-difference sum -------------------
+    if (a.q_out != nullptr) {
+      const f32x4* erow = reinterpret_cast<const f32x4*>(a.E + (size_t)(ok ? bi : 0) * D);
+      float* obase = a.q_out + zoff[ct];
+      float part = 0.0f;
+#pragma unroll
+      for (int m = 0; m < D / 4; ++m) {
+        const f32x4 v = erow[m];
+        const float q0 = h ? v[1] : v[0];
+        const float q1 = h ? v[3] : v[2];
+        const float d0 = q0 - zr[ct][2 * m];
+        const float d1 = q1 - zr[ct][2 * m + 1];
+        part = __builtin_fmaf(d0, d0, part);
+        part = __builtin_fmaf(d1, d1, part);
+        if (ok) {
+          if (NCHW) {
+            obase[(int64_t)(2 * m) * zstride] = zr[ct][2 * m] + d0;
+            obase[(int64_t)(2 * m + 1) * zstride] = zr[ct][2 * m + 1] + d1;
+          } else {
+            obase[4 * m + h] = zr[ct][2 * m] + d0;
+            obase[4 * m + 2 + h] = zr[ct][2 * m + 1] + d1;
+          }
+        }
+      }
+      lp += ok ? part : 0.0f;
+    }
+  }
+
+  // ---- per-workgroup partials (fixed reduction order: reproducible) ---------------------
+  float* red = lds + 2 * STAGE_F;  // 16 floats past the stage buffers
+  if (a.q_out != nullptr && a.loss_partial != nullptr) {
+    const float ws = wave_sum(lp);
+    if (lane == 0) red[wave] = ws;
+    __syncthreads();
+    if (threadIdx.x == 0) a.loss_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+  if (PAIRWISE) {
+    double sd = psum[0] + psum[1];
+    float mn = pmin[0] < pmin[1] ? pmin[0] : pmin[1];
+    float mx = pmax[0] > pmax[1] ? pmax[0] : pmax[1];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      sd += __shfl_xor(sd, off);
+      const float o1 = __shfl_xor(mn, off), o2 = __shfl_xor(mx, off);
+      mn = o1 < mn ? o1 : mn;
+      mx = o2 > mx ? o2 : mx;
+    }
+    double* redd = reinterpret_cast<double*>(red + 4);
+    if (lane == 0) { redd[wave] = sd; red[12 + wave] = mn; red[16 + wave] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      a.pw_sum[blockIdx.x] = (redd[0] + redd[1]) + (redd[2] + redd[3]);
+      float m0 = red[12], m1 = red[16];
+      for (int w = 1; w < 4; ++w) { m0 = red[12 + w] < m0 ? red[12 + w] : m0; m1 = red[16 + w] > m1 ? red[16 + w] : m1; }
+      a.pw_minmax[2 * blockIdx.x] = m0;
+      a.pw_minmax[2 * blockIdx.x + 1] = m1;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Exact scalar search: any D, torch.argmin's NaN rule, literal temperature division.
+// One workgroup handles 8 rows at a time; thread t scans codes t, t+256, ...; the dot
+// product is the same fmaf chain the MFMA computes, so both kernels agree bit for bit on
+// rows both can handle.  Used for rows the MFMA kernel flags (non-finite input), for a
+// flagged codebook, for degenerate temperatures and for shapes outside the MFMA kernel.
+// ---------------------------------------------------------------------------------------
+constexpr int XR = 8;  // rows per pass
+
+__device__ __forceinline__ float z_load(const float* z, bool nchw, int64_t n, int c, int D, int64_t HW) {
+  if (!nchw) return z[n * D + c];
+  const int64_t b = n / HW, hw = n - b * HW;
+  return z[(b * D + c) * HW + hw];
+}
+
+__global__ __launch_bounds__(256) void vq_search_exact_kernel(SearchArgs a, int D, int nchw, int use_list,
+                                                              float* loss_partial_out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* zs = lds;                      // [XR][D]
+  float* z2s = zs + (size_t)XR * D;     // [XR]
+  float* rbest = z2s + XR;              // [XR][256]
+  int* ridx = reinterpret_cast<int*>(rbest + XR * 256);  // [XR][256]
+  const int t = threadIdx.x;
+  const int64_t total = use_list ? (int64_t)a.control[VQ_CTL_NF_COUNT] : a.N;
+  float block_loss = 0.0f;  // meaningful in thread 0
+
+  for (int64_t base = (int64_t)blockIdx.x * XR; base < total; base += (int64_t)gridDim.x * XR) {
+    const int nr = (int)((total - base) < XR ? (total - base) : XR);
+    __syncthreads();
+    for (int i = t; i < XR * D; i += 256) {
+      const int r = i / D, c = i - r * D;
+      float v = 0.0f;
+      if (r < nr) {
+        const int64_t n = use_list ? (int64_t)a.nf_rows[base + r] : base + r;
+        v = z_load(a.z, nchw != 0, n, c, D, a.HW);
+      }
+      zs[i] = v;
+    }
+    __syncthreads();
+    if (t < 2 * XR) {  // squared norms: even-channel chain and odd-channel chain
+      const int r = t >> 1, hh = t & 1;
+      float p = 0.0f;
+      for (int c = hh; c < D; c += 2) p = __builtin_fmaf(zs[r * D + c], zs[r * D + c], p);
+      const float o = __shfl_xor(p, 1);
+      if (hh == 0) z2s[r] = p + o;
+    }
+    __syncthreads();
+
+    float best[XR];
+    int bi[XR];
+#pragma unroll
+    for (int r = 0; r < XR; ++r) { best[r] = 0.0f; bi[r] = -1; }
+    for (int k = t; k < a.K; k += 256) {
+      const float* e = a.E + (size_t)k * D;
+      float dot[XR];
+#pragma unroll
+      for (int r = 0; r < XR; ++r) dot[r] = 0.0f;
+      for (int c = 0; c < D; ++c) {
+        const float ev = e[c];
+#pragma unroll
+        for (int r = 0; r < XR; ++r) dot[r] = __builtin_fmaf(zs[r * D + c], ev, dot[r]);
+      }
+      const float ek = a.e2[k];
+#pragma unroll
+      for (int r = 0; r < XR; ++r) {
+        const float tt = z2s[r] + ek;
+        float d = __builtin_fmaf(-2.0f, dot[r], tt);
+        if (a.T != 1.0f) d = d / a.T;
+        if (bi[r] < 0 || vq_argmin_takes(d, best[r])) { best[r] = d; bi[r] = k; }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < XR; ++r) { rbest[r * 256 + t] = best[r]; ridx[r * 256 + t] = bi[r]; }
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+      if (t < off) {
+#pragma unroll
+        for (int r = 0; r < XR; ++r) {
+          const float d2 = rbest[r * 256 + t + off];
+          const int i2 = ridx[r * 256 + t + off];
+          const float d1 = rbest[r * 256 + t];
+          const int i1 = ridx[r * 256 + t];
+          if (i2 >= 0 && (i1 < 0 || vq_merge_takes(d2, i2, d1, i1))) { rbest[r * 256 + t] = d2; ridx[r * 256 + t] = i2; }
+        }
+      }
+      __syncthreads();
+    }
+    // winners: indices, distances, gather + straight-through + loss
+    float part = 0.0f;
+    for (int r = 0; r < nr; ++r) {
+      const int64_t n = use_list ? (int64_t)a.nf_rows[base + r] : base + r;
+      int w = ridx[r * 256];
+      if (w < 0) w = 0;
+      if (t == 0) {
+        if (a.idx64) a.idx64[n] = (int64_t)w + a.code_base;
+        if (a.idx32) a.idx32[n] = (int32_t)(w + a.code_base);
+        if (a.dmin) a.dmin[n] = rbest[r * 256];
+      }
+      if (a.q_out) {
+        const float* e = a.E + (size_t)w * D;
+        for (int c = t; c < D; c += 256) {
+          const float zv = zs[r * D + c];
+          const float diff = e[c] - zv;
+          part = __builtin_fmaf(diff, diff, part);
+          int64_t off;
+          if (nchw) { const int64_t b = n / a.HW, hw = n - b * a.HW; off = (b * D + c) * a.HW + hw; }
+          else off = n * D + c;
+          a.q_out[off] = zv + diff;
+        }
+      }
+    }
+    if (a.q_out) {
+      __syncthreads();
+      rbest[t] = part;
+      __syncthreads();
+      for (int off = 128; off >= 1; off >>= 1) {
+        if (t < off) rbest[t] += rbest[t + off];
+        __syncthreads();
+      }
+      if (t == 0) block_loss += rbest[0];
+    }
+  }
+  if (t == 0 && loss_partial_out) loss_partial_out[blockIdx.x] = block_loss;
+}
+
+// ---------------------------------------------------------------------------------------
+// Codebook preparation: squared norms + MFMA-fragment image.
+// One wave per 32-code tile; lane (i = lane&31, h = lane>>5) walks row i's channels 2s+h,
+// which is both the even/odd norm chain and the A-operand element order.
+// ---------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(64) void vq_prep_image_kernel(const float* __restrict__ E, int K, float* __restrict__ image,
+                                                           float* __restrict__ e2, int32_t* control) {
+  constexpr int G = D / 8;
+  const int lane = threadIdx.x;
+  const int i = lane & 31, h = lane >> 5;
+  const int tile = blockIdx.x;  // 32 codes
+  const int code = tile * 32 + i;
+  const bool real = code < K;
+  const f32x4* row = reinterpret_cast<const f32x4*>(E + (size_t)(real ? code : 0) * D);
+  const int stage = tile >> 1, rt = tile & 1;
+  float* st_base = image + (size_t)stage * vq_stage_floats(D);
+  f32x4* dst = reinterpret_cast<f32x4*>(st_base + (size_t)rt * 32 * D) + lane;
+  float p = 0.0f;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    f32x4 v0 = row[2 * g], v1 = row[2 * g + 1];
+    if (!real) { v0 = f32x4{0, 0, 0, 0}; v1 = f32x4{0, 0, 0, 0}; }
+    f32x4 o;
+    o[0] = h ? v0[1] : v0[0];
+    o[1] = h ? v0[3] : v0[2];
+    o[2] = h ? v1[1] : v1[0];
+    o[3] = h ? v1[3] : v1[2];
+    dst[g * 64] = o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) p = __builtin_fmaf(o[q], o[q], p);
+  }
+  const float n2 = p + __shfl_xor(p, 32);
+  if (h == 0) {
+    const float v = real ? n2 : __builtin_inff();
+    e2[code] = v;
+    st_base[VQ_STAGE_CODES * D + rt * 32 + i] = v;
+    if (real && !(n2 <= VQ_NORM_LIMIT)) atomicOr(&control[VQ_CTL_CB_FLAG], 1);
+  } else {
+    // zero the unused tail of the norms piece once per stage (keeps the image defined)
+    if (rt == 0) {
+      for (int q = 0; q < 6; ++q) st_base[VQ_STAGE_CODES * D + 64 + q * 32 + i] = 0.0f;
+    }
+  }
+}
+
+// Norms only, any D (shapes that take the exact kernel).
+__global__ __launch_bounds__(256) void vq_prep_norms_kernel(const float* __restrict__ E, int K, int Kpad, int D,
+                                                            float* __restrict__ e2, int32_t* control) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int code = t >> 1, hh = t & 1;
+  if (code >= Kpad) return;  // Kpad is even, both lanes of a pair take the same branch
+  float p = 0.0f;
+  if (code < K) {
+    const float* row = E + (size_t)code * D;
+    for (int c = hh; c < D; c += 2) p = __builtin_fmaf(row[c], row[c], p);
+  }
+  const float o = __shfl_xor(p, 1);
+  if (hh == 0) {
+    const float n2 = p + o;
+    e2[code] = code < K ? n2 : __builtin_inff();
+    if (code < K && !(n2 <= VQ_NORM_LIMIT)) atomicOr(&control[VQ_CTL_CB_FLAG], 1);
+  }
+}
+
+// Standalone gather + straight-through + loss partials for given int64 indices.
+__global__ __launch_bounds__(256) void vq_gather_st_kernel(const float* __restrict__ z, int nchw, int64_t N, int D,
+                                                           int64_t HW, const float* __restrict__ E, int K,
+                                                           const int64_t* __restrict__ idx, float* __restrict__ q_out,
+                                                           float* __restrict__ loss_partial) {
+  // A workgroup owns 256 consecutive rows.  NCHW: thread = row, loop over channels, so the
+  // z loads and q stores of a wave are contiguous along hw; the codebook rows come through
+  // the caches.  ND: a wave walks one row at a time, lanes along channels.
+  __shared__ float red[4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int64_t row0 = (int64_t)blockIdx.x * VQ_WG_ROWS;
+  float part = 0.0f;
+  if (nchw) {
+    const int64_t n = row0 + t;
+    if (n < N) {
+      int64_t k = idx[n];
+      if (k < 0 || k >= K) k = 0;
+      const float* e = E + (size_t)k * D;
+      const int64_t b = n / HW, hw = n - b * HW;
+      const int64_t off0 = b * D * HW + hw;
+      for (int c = 0; c < D; ++c) {
+        const float zv = z[off0 + (int64_t)c * HW];
+        const float diff = e[c] - zv;
+        part = __builtin_fmaf(diff, diff, part);
+        q_out[off0 + (int64_t)c * HW] = zv + diff;
+      }
+    }
+  } else {
+    for (int r = wave; r < VQ_WG_ROWS; r += 4) {
+      const int64_t n = row0 + r;
+      if (n >= N) break;
+      int64_t k = idx[n];
+      if (k < 0 || k >= K) k = 0;
+      const float* e = E + (size_t)k * D;
+      for (int c = lane; c < D; c += 64) {
+        const float zv = z[n * D + c];
+        const float diff = e[c] - zv;
+        part = __builtin_fmaf(diff, diff, part);
+        q_out[n * D + c] = zv + diff;
+      }
+    }
+  }
+  const float ws = wave_sum(part);
+  if (lane == 0) red[wave] = ws;
+  __syncthreads();
+  if (t == 0 && loss_partial) loss_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+template <int D, bool NCHW, bool TEMP, bool PAIRWISE>
+int launch_mfma(const SearchArgs& a, hipStream_t s) {
+  const size_t lds_bytes = 2 * vq_stage_floats(D) * 4 + 128;
+  auto kern = vq_search_mfma_kernel<D, NCHW, TEMP, PAIRWISE>;
+  static bool attr_done[64] = {};  // per instantiation and device
+  int dev = 0;
+  VQ_CHECK_HIP(hipGetDevice(&dev));
+  if (!attr_done[dev & 63]) {
+    VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds_bytes));
+    attr_done[dev & 63] = true;
+  }
+  const int64_t blocks = (a.N + VQ_WG_ROWS - 1) / VQ_WG_ROWS;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_bytes, s, a);
+  return vq_hip_status(hipGetLastError());
+}
+
+template <int D>
+int dispatch_mfma(const SearchArgs& a, bool nchw, bool temp, bool pairwise, hipStream_t s) {
+  if (pairwise) return launch_mfma<D, false, false, true>(a, s);
+  if (nchw) return temp ? launch_mfma<D, true, true, false>(a, s) : launch_mfma<D, true, false, false>(a, s);
+  return temp ? launch_mfma<D, false, true, false>(a, s) : launch_mfma<D, false, false, false>(a, s);
+}
+
+int run_mfma(const SearchArgs& a, int D, bool nchw, bool temp, bool pairwise, hipStream_t s) {
+  switch (D) {
+    case 16: return dispatch_mfma<16>(a, nchw, temp, pairwise, s);
+    case 32: return dispatch_mfma<32>(a, nchw, temp, pairwise, s);
+    case 64: return dispatch_mfma<64>(a, nchw, temp, pairwise, s);
+    case 128: return dispatch_mfma<128>(a, nchw, temp, pairwise, s);
+    case 256: return dispatch_mfma<256>(a, nchw, temp, pairwise, s);
+    default: return VQ_ERR_UNSUPPORTED;
+  }
+}
+
+int run_exact(const SearchArgs& a, int D, bool nchw, bool use_list, float* loss_out, int blocks, hipStream_t s) {
+  const size_t lds_bytes = ((size_t)XR * D + XR + 2 * XR * 256) * 4;
+  static bool attr_done[64] = {};
+  int dev = 0;
+  VQ_CHECK_HIP(hipGetDevice(&dev));
+  if (!attr_done[dev & 63]) {
+    VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vq_search_exact_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)XR * 4096 + XR + 2 * XR * 256) * 4)));
+    attr_done[dev & 63] = true;
+  }
+  hipLaunchKernelGGL(vq_search_exact_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, s, a, D, nchw ? 1 : 0,
+                     use_list ? 1 : 0, loss_out);
+  return vq_hip_status(hipGetLastError());
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+size_t vq_image_bytes(int K, int D) {
+  if (K <= 0 || D <= 0 || !vq_fast_dim(D)) return 256;
+  return (size_t)(vq_kpad(K) / VQ_STAGE_CODES) * vq_stage_floats(D) * 4;
+}
+size_t vq_norms_bytes(int K) { return K > 0 ? (size_t)vq_kpad(K) * 4 : 256; }
+int64_t vq_search_blocks(int64_t N) { return N > 0 ? (N + VQ_WG_ROWS - 1) / VQ_WG_ROWS : 0; }
+size_t vq_loss_partial_bytes(int64_t N) { return (size_t)(vq_search_blocks(N) + VQ_FIX_WGS) * 4; }
+size_t vq_control_bytes(void) { return VQ_CTL_WORDS * 4; }
+
+int vq_control_reset(int32_t* control, void* stream) {
+  if (!control) return VQ_ERR_INVALID_ARG;
+  return vq_hip_status(hipMemsetAsync(control, 0, VQ_CTL_WORDS * 4, (hipStream_t)stream));
+}
+
+int vq_codebook_prep(const float* E, int K, int D, float* image, float* e2, int32_t* control, void* stream) {
+  if (!E || !e2 || !control || K <= 0 || D <= 0) return VQ_ERR_INVALID_ARG;
+  if (D > 4096) return VQ_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const int Kpad = vq_kpad(K);
+  if (vq_fast_dim(D) && image != nullptr) {
+    if (!aligned16(E) || !aligned16(image)) return VQ_ERR_INVALID_ARG;
+    const int tiles = Kpad / 32;
+    switch (D) {
+      case 16: hipLaunchKernelGGL(vq_prep_image_kernel<16>, dim3(tiles), dim3(64), 0, s, E, K, image, e2, control); break;
+      case 32: hipLaunchKernelGGL(vq_prep_image_kernel<32>, dim3(tiles), dim3(64), 0, s, E, K, image, e2, control); break;
+      case 64: hipLaunchKernelGGL(vq_prep_image_kernel<64>, dim3(tiles), dim3(64), 0, s, E, K, image, e2, control); break;
+      case 128: hipLaunchKernelGGL(vq_prep_image_kernel<128>, dim3(tiles), dim3(64), 0, s, E, K, image, e2, control); break;
+      default: hipLaunchKernelGGL(vq_prep_image_kernel<256>, dim3(tiles), dim3(64), 0, s, E, K, image, e2, control); break;
+    }
+  } else {
+    hipLaunchKernelGGL(vq_prep_norms_kernel, dim3((2 * Kpad + 255) / 256), dim3(256), 0, s, E, K, Kpad, D, e2, control);
+  }
+  return vq_hip_status(hipGetLastError());
+}
+
+static int search_common(const float* z, int layout, int64_t N, int D, int64_t HW, const float* E,
+                         const float* image, const float* e2, int K, float temperature, int64_t code_base,
+                         int64_t* idx64, int32_t* idx32, float* dmin, float* q_out, float* loss_partial,
+                         int32_t* nf_rows, int32_t* control, bool force_exact, hipStream_t s) {
+  if (!z || !E || !e2 || N <= 0 || K <= 0 || D <= 0) return VQ_ERR_INVALID_ARG;
+  if (layout != VQ_LAYOUT_ND && layout != VQ_LAYOUT_NCHW) return VQ_ERR_INVALID_ARG;
+  if (layout == VQ_LAYOUT_NCHW && (HW <= 0 || N % HW != 0)) return VQ_ERR_INVALID_ARG;
+  if (D > 4096 || N >= (int64_t)1 << 31 || (int64_t)K + code_base >= (int64_t)1 << 31) return VQ_ERR_UNSUPPORTED;
+  const bool nchw = layout == VQ_LAYOUT_NCHW;
+  SearchArgs a{};
+  a.z = z; a.E = E; a.image = image; a.e2 = e2; a.N = N; a.HW = nchw ? HW : 1; a.K = K;
+  a.nstages = vq_kpad(K) / VQ_STAGE_CODES; a.T = temperature; a.code_base = code_base;
+  a.idx64 = idx64; a.idx32 = idx32; a.dmin = dmin; a.q_out = q_out; a.loss_partial = loss_partial;
+  a.nf_rows = nf_rows; a.control = control;
+  const int64_t blocks = vq_search_blocks(N);
+  // T > 0 and finite keeps the MFMA path (division by it is monotone); anything else is
+  // evaluated literally by the exact kernel.
+  const bool t_regular = temperature > 0.0f && temperature < __builtin_inff();
+  const bool fast = !force_exact && vq_fast_dim(D) && image != nullptr && t_regular && aligned16(z) &&
+                    aligned16(E) && aligned16(image) && idx32 != nullptr && nf_rows != nullptr && control != nullptr;
+  if (fast) {
+    int rc = run_mfma(a, D, nchw, temperature != 1.0f, false, s);
+    if (rc != VQ_OK) return rc;
+    // rows flagged by the MFMA kernel (normally none: the kernel then exits at once)
+    float* fix_loss = loss_partial ? loss_partial + blocks : nullptr;
+    return run_exact(a, D, nchw, true, fix_loss, VQ_FIX_WGS, s);
+  }
+  // exact path for everything: partials [0, blocks) are zeroed, the kernel fills the tail
+  if (loss_partial) VQ_CHECK_HIP(hipMemsetAsync(loss_partial, 0, (size_t)blocks * 4, s));
+  float* fix_loss = loss_partial ? loss_partial + blocks : nullptr;
+  return run_exact(a, D, nchw, false, fix_loss, VQ_FIX_WGS, s);
+}
+
+int vq_search(const float* z, int layout, int64_t N, int D, int64_t HW, const float* E, const float* image,
+              const float* e2, int K, float temperature, int64_t code_base, int64_t* idx64, int32_t* idx32,
+              float* dmin, float* q_out, float* loss_partial, int32_t* nf_rows, int32_t* control, void* stream) {
+  if (!idx32 || !nf_rows || !control) return VQ_ERR_INVALID_ARG;
+  return search_common(z, layout, N, D, HW, E, image, e2, K, temperature, code_base, idx64, idx32, dmin, q_out,
+                       loss_partial, nf_rows, control, false, (hipStream_t)stream);
+}
+
+int vq_search_exact(const float* z, int layout, int64_t N, int D, int64_t HW, const float* E, const float* e2,
+                    int K, float temperature, int64_t code_base, int64_t* idx64, int32_t* idx32, float* dmin,
+                    float* q_out, float* loss_partial, void* stream) {
+  return search_common(z, layout, N, D, HW, E, nullptr, e2, K, temperature, code_base, idx64, idx32, dmin, q_out,
+                       loss_partial, nullptr, nullptr, true, (hipStream_t)stream);
+}
+
+int vq_gather_st(const float* z, int layout, int64_t N, int D, int64_t HW, const float* E, int K,
+                 const int64_t* idx64, float* q_out, float* loss_partial, void* stream) {
+  if (!z || !E || !idx64 || !q_out || N <= 0 || K <= 0 || D <= 0) return VQ_ERR_INVALID_ARG;
+  if (layout == VQ_LAYOUT_NCHW && (HW <= 0 || N % HW != 0)) return VQ_ERR_INVALID_ARG;
+  const int64_t blocks = vq_search_blocks(N);
+  hipLaunchKernelGGL(vq_gather_st_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, z,
+                     layout == VQ_LAYOUT_NCHW ? 1 : 0, N, D, layout == VQ_LAYOUT_NCHW ? HW : 1, E, K, idx64, q_out,
+                     loss_partial);
+  return vq_hip_status(hipGetLastError());
+}
+
+int vq_pairwise_search_launch(const float* E, const float* image, const float* e2, int K, int D, float* nn_dist,
+                              int64_t* nn_idx, int32_t* idx32, double* sum_partial, float* mm_partial,
+                              int32_t* nf_rows, int32_t* control, void* stream) {
+  // internal helper of vq_pairwise_stats (vq_stats.hip); not part of the public header
+  SearchArgs a{};
+  a.z = E; a.E = E; a.image = image; a.e2 = e2; a.N = K; a.HW = 1; a.K = K;
+  a.nstages = vq_kpad(K) / VQ_STAGE_CODES; a.T = 1.0f; a.code_base = 0;
+  a.idx64 = nn_idx; a.idx32 = idx32; a.dmin = nn_dist; a.q_out = nullptr; a.loss_partial = nullptr;
+  a.nf_rows = nf_rows; a.control = control; a.pw_sum = sum_partial; a.pw_minmax = mm_partial;
+  return run_mfma(a, D, false, false, true, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,236 @@
+// Codebook statistics for gfx950: cluster-size stats, index (histogram) stats, pairwise
+// codebook distances, and the (distance, index) packing of the row-sharded search.
+//
+// Replaces vqvae/ema_vector_quantizer.py:205-232, vqvae/codebook_utilization_check.py:83-108
+// and vqvae/vqgan_trainer.py:594-612 of the reference.  The K-sized reductions run in one
+// workgroup with a fixed tree, so results are reproducible; nothing here syncs with the host.
+#include "vq_common.h"
+
+namespace {
+
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+  const int t = threadIdx.x;
+  sh[t] = v;
+  __syncthreads();
+  for (int off = 512; off >= 1; off >>= 1) {
+    if (t < off) sh[t] += sh[t + off];
+    __syncthreads();
+  }
+  const double r = sh[0];
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(1024) void vq_cluster_stats_kernel(const float* __restrict__ cs, const float* __restrict__ usage,
+                                                                int K, double* __restrict__ out) {
+  __shared__ double sh[1024];
+  const int t = threadIdx.x;
+  double act = 0.0, tot = 0.0, use = 0.0;
+  for (int k = t; k < K; k += 1024) {
+    act += cs[k] > 0.0f ? 1.0 : 0.0;
+    tot += (double)cs[k];
+    use += (double)usage[k];
+  }
+  act = block_sum(act, sh);
+  tot = block_sum(tot, sh);
+  use = block_sum(use, sh);
+  double ent = 0.0;
+  if (act > 0.0) {
+    const float totf = (float)tot;
+    double e = 0.0;
+    for (int k = t; k < K; k += 1024) {
+      const float p = cs[k] / totf;
+      e -= (double)(p * log2f(p + 1e-10f));
+    }
+    ent = block_sum(e, sh);
+  }
+  if (t == 0) {
+    const float entf = (float)ent;
+    out[0] = act;
+    out[1] = act / (double)K;
+    out[2] = act > 0.0 ? (double)entf : 0.0;
+    out[3] = act > 0.0 ? (double)entf / (double)log2f((float)K) : 0.0;
+    out[4] = (double)(float)use;
+  }
+}
+
+__global__ __launch_bounds__(1024) void vq_index_stats_kernel(const uint32_t* __restrict__ counts, int K, int64_t M,
+                                                              double* __restrict__ out64, float* __restrict__ out32) {
+  __shared__ double sh[1024];
+  const int t = threadIdx.x;
+  double uniq = 0.0, total = 0.0;
+  for (int k = t; k < K; k += 1024) {
+    uniq += counts[k] > 0 ? 1.0 : 0.0;
+    total += (double)counts[k];
+  }
+  uniq = block_sum(uniq, sh);
+  total = block_sum(total, sh);
+  if (out64) {
+    // float64, like the NumPy code: p = counts / len(all_indices)
+    double e = 0.0, ps = 0.0;
+    for (int k = t; k < K; k += 1024)
+      if (counts[k] > 0) {
+        const double p = (double)counts[k] / (double)M;
+        e -= p * log2(p + 1e-10);
+        ps += p;
+      }
+    const double ent = block_sum(e, sh);
+    const double psum = block_sum(ps, sh);
+    double g = 0.0;
+    const double mean = uniq > 0.0 ? psum / uniq : 1.0;
+    for (int k = t; k < K; k += 1024)
+      if (counts[k] > 0) {
+        const double r = ((double)counts[k] / (double)M) / mean;
+        g += r * r;
+      }
+    const double gs = block_sum(g, sh);
+    if (t == 0) {
+      out64[0] = uniq;
+      out64[1] = uniq / (double)K;
+      out64[2] = ent;
+      out64[3] = ent / log2((double)K);
+      out64[4] = uniq > 0.0 ? 1.0 - gs / uniq : 0.0;
+    }
+  }
+  if (out32) {
+    // fp32, like the torch code: probs = counts / sum(counts)
+    const float totf = (float)total;
+    double e = 0.0;
+    for (int k = t; k < K; k += 1024)
+      if (counts[k] > 0) {
+        const float p = (float)counts[k] / totf;
+        if (p > 0.0f) e -= (double)(p * log2f(p + 1e-10f));
+      }
+    const double ent = block_sum(e, sh);
+    if (t == 0) {
+      out32[0] = (float)uniq;
+      out32[1] = (float)uniq / (float)K;
+      out32[2] = (float)ent;
+      out32[3] = (float)ent / log2f((float)K);
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void vq_pairwise_finish_kernel(const double* __restrict__ sum_partial,
+                                                                  const float* __restrict__ mm_partial, int64_t nblocks,
+                                                                  int K, const int32_t* __restrict__ control,
+                                                                  double* __restrict__ out) {
+  __shared__ double sh[1024];
+  __shared__ float shmn[1024], shmx[1024];
+  const int t = threadIdx.x;
+  if (control[VQ_CTL_CB_FLAG] != 0 || control[VQ_CTL_NF_COUNT] != 0) {
+    if (t == 0) { const double nan = __builtin_nan(""); out[0] = nan; out[1] = nan; out[2] = nan; }
+    return;
+  }
+  double s = 0.0;
+  float mn = __builtin_inff(), mx = -__builtin_inff();
+  for (int64_t i = t; i < nblocks; i += 1024) {
+    s += sum_partial[i];
+    mn = mm_partial[2 * i] < mn ? mm_partial[2 * i] : mn;
+    mx = mm_partial[2 * i + 1] > mx ? mm_partial[2 * i + 1] : mx;
+  }
+  const double tot = block_sum(s, sh);
+  shmn[t] = mn; shmx[t] = mx;
+  __syncthreads();
+  for (int off = 512; off >= 1; off >>= 1) {
+    if (t < off) {
+      shmn[t] = shmn[t + off] < shmn[t] ? shmn[t + off] : shmn[t];
+      shmx[t] = shmx[t + off] > shmx[t] ? shmx[t + off] : shmx[t];
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    out[0] = (double)shmn[0];
+    out[1] = K > 1 ? tot / ((double)K * (double)(K - 1)) : 0.0;
+    out[2] = (double)shmx[0];
+  }
+}
+
+__device__ __forceinline__ uint32_t ordered_key(float d) {
+  if (d != d) return 0u;  // NaN sorts first, as torch.argmin treats it
+  const uint32_t u = __float_as_uint(d);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void vq_pack_kernel(const float* __restrict__ dmin, const int64_t* __restrict__ idx,
+                                                      int64_t N, uint64_t* __restrict__ packed) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < N) packed[i] = ((uint64_t)ordered_key(dmin[i]) << 32) | (uint64_t)(uint32_t)idx[i];
+}
+
+__global__ __launch_bounds__(256) void vq_unpack_kernel(const uint64_t* __restrict__ packed, int64_t N,
+                                                        float* __restrict__ dmin, int64_t* __restrict__ idx64,
+                                                        int32_t* __restrict__ idx32) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const uint64_t p = packed[i];
+  const uint32_t key = (uint32_t)(p >> 32);
+  const uint32_t id = (uint32_t)p;
+  if (dmin) {
+    float d;
+    if (key == 0u) d = __builtin_nanf("");
+    else d = __uint_as_float((key & 0x80000000u) ? (key ^ 0x80000000u) : ~key);
+    dmin[i] = d;
+  }
+  if (idx64) idx64[i] = (int64_t)id;
+  if (idx32) idx32[i] = (int32_t)id;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vq_cluster_stats(const float* cluster_size, const float* usage, int K, double* out, void* stream) {
+  if (!cluster_size || !usage || !out || K <= 0) return VQ_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(vq_cluster_stats_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, cluster_size, usage, K, out);
+  return vq_hip_status(hipGetLastError());
+}
+
+int vq_index_stats(const uint32_t* counts, int K, int64_t M, double* out64, float* out32, void* stream) {
+  if (!counts || K <= 0 || M <= 0 || (!out64 && !out32)) return VQ_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(vq_index_stats_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, K, M, out64, out32);
+  return vq_hip_status(hipGetLastError());
+}
+
+int vq_pairwise_stats(const float* E, const float* image, const float* e2, int K, int D, float* nn_dist,
+                      int64_t* nn_idx, double* sum_partial, float* mm_partial, double* out, int32_t* control,
+                      void* stream) {
+  if (!E || !image || !e2 || !nn_dist || !nn_idx || !sum_partial || !mm_partial || !out || !control || K <= 0)
+    return VQ_ERR_INVALID_ARG;
+  if (!vq_fast_dim(D)) return VQ_ERR_UNSUPPORTED;
+  // rows with a non-finite norm are appended behind the min/max partials (scratch of K ints)
+  int32_t* nf_rows = reinterpret_cast<int32_t*>(mm_partial + 2 * vq_search_blocks(K));
+  int rc = vq_pairwise_search_launch(E, image, e2, K, D, nn_dist, nn_idx, nullptr, sum_partial, mm_partial, nf_rows,
+                                     control, stream);
+  if (rc != VQ_OK) return rc;
+  hipLaunchKernelGGL(vq_pairwise_finish_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, sum_partial, mm_partial,
+                     vq_search_blocks(K), K, control, out);
+  return vq_hip_status(hipGetLastError());
+}
+
+int vq_pack_dist_index(const float* dmin, const int64_t* idx64, int64_t N, uint64_t* packed, void* stream) {
+  if (!dmin || !idx64 || !packed || N <= 0) return VQ_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(vq_pack_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dmin, idx64,
+                     N, packed);
+  return vq_hip_status(hipGetLastError());
+}
+
+int vq_unpack_dist_index(const uint64_t* packed, int64_t N, float* dmin, int64_t* idx64, int32_t* idx32,
+                         void* stream) {
+  if (!packed || N <= 0) return VQ_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(vq_unpack_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, packed, N,
+                     dmin, idx64, idx32);
+  return vq_hip_status(hipGetLastError());
+}
+
+int vq_version(void) { return 100; }
+
+const char* vq_status_string(int status) {
+  if (status == VQ_OK) return "ok";
+  if (status == VQ_ERR_INVALID_ARG) return "invalid argument";
+  if (status == VQ_ERR_UNSUPPORTED) return "unsupported shape";
+  if (status >= VQ_ERR_HIP_BASE) return hipGetErrorString((hipError_t)(status - VQ_ERR_HIP_BASE));
+  return "unknown status";
+}
+
+}  // extern "C"

@@ -1,0 +1,267 @@
+"""Host-side operators over libvqhip.so: torch tensors in, HIP kernels on the current stream.
+
+PyTorch is used for device memory and streams only.  Every function here requires CUDA
+(ROCm) tensors and raises otherwise; there is no CPU path.  The functions mirror the steps
+of the reference's ``EMAVectorQuantizer.forward`` (vqvae/ema_vector_quantizer.py:33-108).
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import LAYOUT_NCHW, LAYOUT_ND, check
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _require_cuda(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU: the quantizer runs only as HIP kernels on MI355X "
+                           f"(got a tensor on '{t.device}')")
+
+
+def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    _require_cuda(t, name)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def ema_scalars(K: int, decay: float, epsilon: float):
+    """The four fp32 constants of the EMA update, rounded as the reference's Python expressions
+    round when they meet an fp32 tensor (vqvae/ema_vector_quantizer.py:71-79)."""
+    return (float(np.float32(decay)), float(np.float32(1 - decay)), float(np.float32(epsilon)),
+            float(np.float32(K * epsilon)))
+
+
+@dataclass
+class Workspace:
+    """Grow-only device buffers reused from call to call (never part of a state_dict)."""
+    device: torch.device
+    _bufs: dict = field(default_factory=dict)
+
+    def get(self, name: str, nbytes: int, dtype=torch.uint8) -> torch.Tensor:
+        nbytes = max(int(nbytes), 256)
+        buf = self._bufs.get(name)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._bufs[name] = buf
+        item = torch.empty((), dtype=dtype).element_size()
+        return buf[: nbytes // item * item].view(dtype)
+
+
+@dataclass
+class StepResult:
+    quantized: torch.Tensor       # straight-through output, layout of z
+    loss: torch.Tensor            # 0-dim
+    perplexity: torch.Tensor      # 0-dim
+    indices: torch.Tensor         # [N] int64
+    counts: torch.Tensor          # [K] int32 bit pattern of uint32 counts
+    dmin: Optional[torch.Tensor] = None
+
+
+def _shape_of(z: torch.Tensor, D: int):
+    if z.dim() == 4:
+        B, C, H, W = z.shape
+        if C != D:
+            # same exception type the reference's .view(-1, D) raises on a channel mismatch
+            raise RuntimeError(f"shape '[-1, {D}]' is invalid for input with {C} channels "
+                               f"(expected (B, {D}, H, W))")
+        return LAYOUT_NCHW, B * H * W, H * W
+    if z.dim() == 2:
+        if z.shape[1] != D:
+            raise RuntimeError(f"shape '[-1, {D}]' is invalid for input of size {tuple(z.shape)}")
+        return LAYOUT_ND, z.shape[0], 1
+    raise RuntimeError(f"expected (B, C, H, W) or (N, D) latents, got {tuple(z.shape)}")
+
+
+def prepare_codebook(E: torch.Tensor, ws: Workspace):
+    """vq_codebook_prep: squared norms + MFMA image of the codebook.  Returns (image, e2, control)."""
+    lib = _lib.load()
+    K, D = E.shape
+    image = ws.get("image", lib.vq_image_bytes(K, D), torch.float32)
+    e2 = ws.get("e2", lib.vq_norms_bytes(K), torch.float32)
+    control = ws.get("control", lib.vq_control_bytes(), torch.int32)
+    s = _stream(E.device)
+    check(lib.vq_control_reset(_ptr(control), s), "vq_control_reset")
+    check(lib.vq_codebook_prep(_ptr(E), K, D, _ptr(image), _ptr(e2), _ptr(control), s), "vq_codebook_prep")
+    return image, e2, control
+
+
+def search(z: torch.Tensor, E: torch.Tensor, ws: Workspace, temperature: float = 1.0, code_base: int = 0,
+           want_quantized: bool = True, want_dmin: bool = False, exact: bool = False, prepared=None):
+    """Nearest-codebook search (+ fused gather / straight-through / loss partials).
+
+    Returns dict(indices int64 [N], idx32, dmin|None, quantized|None, loss_partial|None, n_partial).
+    """
+    lib = _lib.load()
+    z = _f32c(z, "latents")
+    E = _f32c(E, "codebook")
+    K, D = E.shape
+    layout, N, HW = _shape_of(z, D)
+    image, e2, control = prepared if prepared is not None else prepare_codebook(E, ws)
+    dev = z.device
+    idx64 = torch.empty(N, dtype=torch.int64, device=dev)
+    idx32 = ws.get("idx32", N * 4, torch.int32)
+    dmin = torch.empty(N, dtype=torch.float32, device=dev) if want_dmin else None
+    q = torch.empty_like(z) if want_quantized else None
+    n_partial = lib.vq_loss_partial_bytes(N) // 4
+    lp = ws.get("loss_partial", n_partial * 4, torch.float32) if want_quantized else None
+    s = _stream(dev)
+    if exact:
+        check(lib.vq_search_exact(_ptr(z), layout, N, D, HW, _ptr(E), _ptr(e2), K, float(temperature), code_base,
+                                  _ptr(idx64), _ptr(idx32), _ptr(dmin), _ptr(q), _ptr(lp), s), "vq_search_exact")
+    else:
+        nf_rows = ws.get("nf_rows", N * 4, torch.int32)
+        check(lib.vq_search(_ptr(z), layout, N, D, HW, _ptr(E), _ptr(image), _ptr(e2), K, float(temperature),
+                            code_base, _ptr(idx64), _ptr(idx32), _ptr(dmin), _ptr(q), _ptr(lp), _ptr(nf_rows),
+                            _ptr(control), s), "vq_search")
+    return {"indices": idx64, "idx32": idx32, "dmin": dmin, "quantized": q, "loss_partial": lp,
+            "n_partial": n_partial, "layout": layout, "N": N, "HW": HW, "control": control}
+
+
+def histogram(idx: torch.Tensor, K: int, ws: Workspace, out: Optional[torch.Tensor] = None,
+              accumulate: bool = False) -> torch.Tensor:
+    """counts[k] = #(idx == k) as an int32 tensor holding uint32 bit patterns."""
+    lib = _lib.load()
+    _require_cuda(idx, "indices")
+    if idx.dtype not in (torch.int32, torch.int64):
+        idx = idx.long()
+    idx = idx.contiguous().view(-1)
+    counts = out if out is not None else torch.empty(K, dtype=torch.int32, device=idx.device)
+    control = ws.get("control", lib.vq_control_bytes(), torch.int32)
+    check(lib.vq_code_histogram(_ptr(idx), 1 if idx.dtype == torch.int64 else 0, idx.numel(), K, _ptr(counts),
+                                1 if accumulate else 0, _ptr(control), _stream(idx.device)), "vq_code_histogram")
+    return counts
+
+
+def embed_sums(z: torch.Tensor, idx32: torch.Tensor, K: int, ws: Workspace):
+    """vq_ema_scatter: returns (slabs [nslab, K, D], nslab)."""
+    lib = _lib.load()
+    z = _f32c(z, "latents")
+    D = z.shape[1]
+    layout, N, HW = _shape_of(z, D)
+    nslab = lib.vq_scatter_slabs(N, K, D)
+    slabs = ws.get("slabs", nslab * K * D * 4, torch.float32)[: nslab * K * D].view(nslab, K, D)
+    check(lib.vq_ema_scatter(_ptr(z), layout, N, D, HW, _ptr(idx32), K, _ptr(slabs), _stream(z.device)),
+          "vq_ema_scatter")
+    return slabs, nslab
+
+
+def reduce_slabs(slabs: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = _lib.load()
+    nslab, K, D = slabs.shape
+    dw = out if out is not None else torch.empty(K, D, dtype=torch.float32, device=slabs.device)
+    check(lib.vq_reduce_slabs(_ptr(slabs), nslab, K, D, _ptr(dw), _stream(slabs.device)), "vq_reduce_slabs")
+    return dw
+
+
+def step_scalars(loss_partial, n_partial: int, N_total: int, D: int, beta: float, counts, K: int, device,
+                 want_sq_sum: bool = False):
+    """loss = beta * mean((q - z)^2) and perplexity, as 0-dim device tensors."""
+    lib = _lib.load()
+    loss = torch.empty((), dtype=torch.float32, device=device) if loss_partial is not None else None
+    perp = torch.empty((), dtype=torch.float32, device=device) if counts is not None else None
+    sq = torch.empty((), dtype=torch.float64, device=device) if want_sq_sum else None
+    check(lib.vq_step_scalars(_ptr(loss_partial), n_partial, N_total, D, float(np.float32(beta)), _ptr(counts), K,
+                              _ptr(loss), _ptr(perp), _ptr(sq), _stream(device)), "vq_step_scalars")
+    return loss, perp, sq
+
+
+def ema_update(counts, slabs: torch.Tensor, usage, cluster_size, ema_w, E, decay: float, epsilon: float,
+               counts64=None) -> None:
+    """In-place EMA update of usage_count, ema_cluster_size, ema_w and the codebook
+    (vqvae/ema_vector_quantizer.py:65-89)."""
+    lib = _lib.load()
+    K, D = E.shape
+    d, omd, eps, keps = ema_scalars(K, decay, epsilon)
+    s = _stream(E.device)
+    if slabs.dim() == 2:
+        slabs = slabs.unsqueeze(0)
+    check(lib.vq_ema_cluster_update(_ptr(counts), _ptr(counts64), K, d, omd, eps, keps, _ptr(usage),
+                                    _ptr(cluster_size), s), "vq_ema_cluster_update")
+    check(lib.vq_ema_codebook_update(_ptr(slabs), slabs.shape[0], K, D, d, omd, _ptr(cluster_size), _ptr(ema_w),
+                                     _ptr(E), s), "vq_ema_codebook_update")
+
+
+def backward(grad_q, grad_loss, z, q_st, coef: float) -> torch.Tensor:
+    lib = _lib.load()
+    grad_z = torch.empty_like(z)
+    gq = None if grad_q is None else _f32c(grad_q, "grad_quantized")
+    gl = None if grad_loss is None else _f32c(grad_loss, "grad_loss")
+    check(lib.vq_backward(_ptr(gq), _ptr(gl), _ptr(z), _ptr(q_st), z.numel(), float(coef), _ptr(grad_z),
+                          _stream(z.device)), "vq_backward")
+    return grad_z
+
+
+def onehot(idx64: torch.Tensor, K: int) -> torch.Tensor:
+    """Dense [N, K] fp32 one-hot matrix (vqvae/ema_vector_quantizer.py:54-55)."""
+    lib = _lib.load()
+    _require_cuda(idx64, "indices")
+    idx64 = idx64.contiguous().view(-1)
+    N = idx64.numel()
+    enc = torch.empty(N, K, dtype=torch.float32, device=idx64.device)
+    check(lib.vq_onehot(_ptr(idx64), N, K, _ptr(enc), _stream(idx64.device)), "vq_onehot")
+    return enc
+
+
+def gather_st(z: torch.Tensor, E: torch.Tensor, idx64: torch.Tensor, ws: Workspace):
+    """Standalone gather + straight-through + loss partials.  Returns (q_st, loss_partial, n_partial)."""
+    lib = _lib.load()
+    z = _f32c(z, "latents")
+    E = _f32c(E, "codebook")
+    K, D = E.shape
+    layout, N, HW = _shape_of(z, D)
+    q = torch.empty_like(z)
+    n_partial = lib.vq_search_blocks(N)
+    lp = ws.get("loss_partial", lib.vq_loss_partial_bytes(N), torch.float32)
+    check(lib.vq_gather_st(_ptr(z), layout, N, D, HW, _ptr(E), K, _ptr(idx64), _ptr(q), _ptr(lp), _stream(z.device)),
+          "vq_gather_st")
+    return q, lp, n_partial
+
+
+def quantize_step(z: torch.Tensor, E: torch.Tensor, ema_w, cluster_size, usage, *, beta: float, decay: float,
+                  epsilon: float, temperature: float, training: bool, ws: Workspace, want_dmin: bool = False,
+                  stats_reduce=None) -> StepResult:
+    """One full forward of the quantizer: search, gather, loss, histogram, perplexity and, in
+    training mode, the EMA update of (usage, cluster_size, ema_w, E) in place.
+
+    ``stats_reduce(counts_i32, dw_or_None, N_local) -> (counts_i64, dw, N_total)`` is the hook of the
+    data-parallel mode: it sums the EMA statistics over ranks before the update (the exchange
+    sits between :65/:84 and :71-89 of the reference's forward).  The commitment loss stays the
+    local-batch mean, as it would under DistributedDataParallel.
+    """
+    K, D = E.shape
+    r = search(z, E, ws, temperature=temperature, want_quantized=True, want_dmin=want_dmin)
+    N = r["N"]
+    counts = ws.get("counts", K * 4, torch.int32)
+    histogram(r["idx32"][:N], K, ws, out=counts)
+    loss, perp, _ = step_scalars(r["loss_partial"], r["n_partial"], N, D, beta,
+                                 counts if stats_reduce is None else None, K, z.device)
+    if stats_reduce is None:
+        if training:
+            slabs, _ = embed_sums(_f32c(z, "latents"), r["idx32"], K, ws)
+            ema_update(counts, slabs, usage, cluster_size, ema_w, E, decay, epsilon)
+    else:
+        dw = None
+        if training:
+            slabs, _ = embed_sums(_f32c(z, "latents"), r["idx32"], K, ws)
+            dw = reduce_slabs(slabs, out=ws.get("dw", K * D * 4, torch.float32)[: K * D].view(K, D))
+        counts64, dw, n_total = stats_reduce(counts, dw, N)
+        # perplexity and the EMA update come from the reduced statistics, so every rank computes
+        # bit-identical values and the replicas stay in step without a broadcast
+        _, perp, _ = step_scalars(None, 0, n_total, D, beta, counts64.to(torch.int32), K, z.device)
+        if training:
+            ema_update(None, dw, usage, cluster_size, ema_w, E, decay, epsilon, counts64=counts64)
+    return StepResult(r["quantized"], loss, perp, r["indices"], counts, r["dmin"])
