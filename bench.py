@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""Benchmark of the quantizer hot path: fused quantize + EMA update, K=8192, D=256, fp32.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--rows ROWS_PER_GPU]
+
+One step = one training forward of the quantizer over one batch of synthetic latents already
+resident in HBM: codebook prep, MFMA nearest-code search fused with gather / straight-through /
+loss, code histogram, EMA embedding sums, scalars, EMA cluster + codebook update (and, for
+N > 1, the RCCL all-reduce of the EMA statistics).  Workload = BASELINE config 2: 4 Mi latent
+vectors per GPU presented as (4096, 256, 32, 32) NCHW.  N > 1 is launched by
+torch.distributed.run, one rank per GPU, rows sharded data-parallel (weak scaling).
+
+Prints ONE JSON line on rank 0 with the throughput, the roofline of the dominant kernel
+(HIP events around every search launch inside the timed region) and, at N = 1, a CPU
+baseline: the dense one-hot PyTorch formulation timed on the host cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+K, D = 8192, 256
+H = W = 32
+BETA, DECAY, EPS = 3.0, 0.95, 1e-5
+PEAK_FP32_MFMA_TFLOPS = 157.3   # dense fp32 matrix peak of MI355X (256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz)
+
+
+def cpu_baseline(rows: int = 16384, reps: int = 3) -> dict:
+    """The reference's dense formulation (oracle/dense_port.py) on the host cores.
+    Sample: `rows` latent vectors (N x K fp32 matrices must fit host memory), `reps` steps."""
+    from oracle.dense_port import dense_forward, new_state
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(0)
+    z = torch.randn(rows // (H * W), D, H, W, generator=g)
+    E = torch.randn(K, D, generator=torch.Generator().manual_seed(1))
+    st = new_state(E)
+    dense_forward(z, st, BETA, DECAY, EPS, 1.0, True)  # warm-up
+    times = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        dense_forward(z, st, BETA, DECAY, EPS, 1.0, True)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": rows / med, "unit": "vectors/s", "cores": threads, "kind": "port",
+            "sample": f"dense one-hot PyTorch formulation of the reference forward+EMA, K={K} D={D}, "
+                      f"{rows} vectors/step, median of {reps} steps ({med:.3f} s/step), torch {torch.__version__} CPU"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=4 * 1024 * 1024, help="latent vectors per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+    from vq_vae_amd import ops
+    from vq_vae_amd.distributed import make_stats_reduce
+
+    stats_reduce = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+        stats_reduce = make_stats_reduce()
+
+    rows = args.rows // (H * W) * (H * W)
+    B = rows // (H * W)
+    # synthetic latents N(0,1) (seed 0 + rank); codebook from a separate N(0,1) stream (seed 1, same on
+    # every rank) so that codes and latents share a scale and utilisation is high
+    gz = torch.Generator(device=dev).manual_seed(rank)
+    z = torch.randn(B, D, H, W, device=dev, generator=gz)
+    ge = torch.Generator(device=dev).manual_seed(1)
+    E = torch.randn(K, D, device=dev, generator=ge)
+    ema_w = torch.zeros(K, D, device=dev)
+    cs = torch.zeros(K, device=dev)
+    usage = torch.zeros(K, device=dev)
+    ws = ops.Workspace(dev)
+
+    ev_pairs = []
+
+    def step(timed: bool):
+        ev = None
+        if timed:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev_pairs.append(ev)
+        return ops.quantize_step(z, E, ema_w, cs, usage, beta=BETA, decay=DECAY, epsilon=EPS, temperature=1.0,
+                                 training=True, ws=ws, stats_reduce=stats_reduce, search_events=ev)
+
+    for _ in range(args.warmup):
+        out = step(False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    search_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_pairs]))
+    flops = 2.0 * rows * K * D                       # algorithmic: one N x K x D contraction per step
+    achieved = flops / (search_ms * 1e-3) / 1e12
+    # sanity of the last step's outputs (cheap; outside the timed region)
+    assert out.indices.shape[0] == rows and bool(torch.isfinite(out.loss)) and bool(torch.isfinite(out.perplexity))
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        line = {
+            "metric": "quantized latent vectors/sec (argmin+EMA update), K=8192 D=256",
+            "value": rows * world * args.steps / elapsed,
+            "unit": "vectors/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"fused quantize+EMA update, K={K}, D={D}, {rows} latent vectors per GPU as "
+                                   f"({B},{D},{H},{W}) NCHW fp32, N(0,1) latents and codebook, decay {DECAY}",
+                       "rows_per_gpu": rows, "parallelism": f"dp{world}" if world > 1 else "single"},
+            "roofline": {"bound": "mfma", "kernel": "vq_search_mfma_kernel<256,NCHW>", "achieved": achieved,
+                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                         "traffic": None, "ms_per_launch": search_ms,
+                         "flops_per_launch": flops},
+            "perplexity": float(out.perplexity.item()),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -184,13 +184,13 @@ int vq_pairwise_stats(const float* E, const float* image, const float* e2, int K
                       void* stream);
 
 /*
- * Codebook-row-sharded search support: pack (distance, index) into one uint64 whose
- * unsigned order is the order torch.argmin would see on the unsharded distance matrix
+ * Codebook-row-sharded search support: pack (distance, index) into one int64 whose
+ * signed order is the order torch.argmin would see on the unsharded distance matrix
  * (NaN first, then ascending distance, then ascending index), and unpack the winner after
- * an all-reduce(MIN).  ref: vqvae/ema_vector_quantizer.py:53 applied across shards.
+ * an all-reduce(MIN) over int64.  ref: vqvae/ema_vector_quantizer.py:53 applied across shards.
  */
-int vq_pack_dist_index(const float* dmin, const int64_t* idx64, int64_t N, uint64_t* packed, void* stream);
-int vq_unpack_dist_index(const uint64_t* packed, int64_t N, float* dmin, int64_t* idx64, int32_t* idx32,
+int vq_pack_dist_index(const float* dmin, const int64_t* idx64, int64_t N, int64_t* packed, void* stream);
+int vq_unpack_dist_index(const int64_t* packed, int64_t N, float* dmin, int64_t* idx64, int32_t* idx32,
                          void* stream);
 
 #ifdef __cplusplus

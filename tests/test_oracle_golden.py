@@ -148,3 +148,21 @@ def test_headline_codebook_shape():
         assert rel_err(st.ema_cluster_size, g["state_ema_cluster_size"]) <= TOL
         assert np.array_equal(st.usage_count, g["state_usage_count"])
         assert abs(st.embedding.astype(np.float64).sum() - g["embedding_sum"]) <= TOL * g["embedding_abs_sum"]
+
+
+def test_dense_port_matches_golden():
+    """The dense one-hot torch formulation (the benchmark's CPU baseline) reproduces the
+    reference's outputs on golden vector g6 (BASELINE config 1)."""
+    import torch
+    from oracle.dense_port import dense_forward, new_state
+    g = load("g6_config1.npz")
+    K, D = 512, 64
+    z = torch.from_numpy(gauss(int(g["z_seed"]), (16, D, 16, 16)))
+    E = torch.from_numpy(gauss(int(g["E_seed"]), (K, D)) * np.float32(g["E_scale"]))
+    st = new_state(E)
+    q, loss, perp, idx = dense_forward(z, st, 3.0)
+    assert np.array_equal(idx.numpy().ravel(), g["indices"].astype(np.int64).ravel())
+    assert abs(loss.item() - g["loss"]) <= 1e-6 * abs(g["loss"])
+    assert abs(perp.item() - g["perplexity"]) <= 1e-6 * abs(g["perplexity"])
+    assert rel_err(st["cs"].numpy(), g["state_ema_cluster_size"]) <= 1e-6
+    assert rel_err(st["E"][:8].numpy(), g["state_embedding_weight_rows"]) <= 1e-6

@@ -153,17 +153,19 @@ __device__ __forceinline__ uint32_t ordered_key(float d) {
 }
 
 __global__ __launch_bounds__(256) void vq_pack_kernel(const float* __restrict__ dmin, const int64_t* __restrict__ idx,
-                                                      int64_t N, uint64_t* __restrict__ packed) {
+                                                      int64_t N, int64_t* __restrict__ packed) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < N) packed[i] = ((uint64_t)ordered_key(dmin[i]) << 32) | (uint64_t)(uint32_t)idx[i];
+  // top bit flipped: the SIGNED order of the key is the intended order (int64 MIN all-reduce)
+  if (i < N)
+    packed[i] = (int64_t)((((uint64_t)ordered_key(dmin[i]) << 32) | (uint64_t)(uint32_t)idx[i]) ^ 0x8000000000000000ull);
 }
 
-__global__ __launch_bounds__(256) void vq_unpack_kernel(const uint64_t* __restrict__ packed, int64_t N,
+__global__ __launch_bounds__(256) void vq_unpack_kernel(const int64_t* __restrict__ packed, int64_t N,
                                                         float* __restrict__ dmin, int64_t* __restrict__ idx64,
                                                         int32_t* __restrict__ idx32) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= N) return;
-  const uint64_t p = packed[i];
+  const uint64_t p = (uint64_t)packed[i] ^ 0x8000000000000000ull;
   const uint32_t key = (uint32_t)(p >> 32);
   const uint32_t id = (uint32_t)p;
   if (dmin) {
@@ -208,14 +210,14 @@ int vq_pairwise_stats(const float* E, const float* image, const float* e2, int K
   return vq_hip_status(hipGetLastError());
 }
 
-int vq_pack_dist_index(const float* dmin, const int64_t* idx64, int64_t N, uint64_t* packed, void* stream) {
+int vq_pack_dist_index(const float* dmin, const int64_t* idx64, int64_t N, int64_t* packed, void* stream) {
   if (!dmin || !idx64 || !packed || N <= 0) return VQ_ERR_INVALID_ARG;
   hipLaunchKernelGGL(vq_pack_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dmin, idx64,
                      N, packed);
   return vq_hip_status(hipGetLastError());
 }
 
-int vq_unpack_dist_index(const uint64_t* packed, int64_t N, float* dmin, int64_t* idx64, int32_t* idx32,
+int vq_unpack_dist_index(const int64_t* packed, int64_t N, float* dmin, int64_t* idx64, int32_t* idx32,
                          void* stream) {
   if (!packed || N <= 0) return VQ_ERR_INVALID_ARG;
   hipLaunchKernelGGL(vq_unpack_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, packed, N,

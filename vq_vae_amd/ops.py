@@ -100,7 +100,8 @@ def prepare_codebook(E: torch.Tensor, ws: Workspace):
 
 
 def search(z: torch.Tensor, E: torch.Tensor, ws: Workspace, temperature: float = 1.0, code_base: int = 0,
-           want_quantized: bool = True, want_dmin: bool = False, exact: bool = False, prepared=None):
+           want_quantized: bool = True, want_dmin: bool = False, exact: bool = False, prepared=None,
+           events=None):
     """Nearest-codebook search (+ fused gather / straight-through / loss partials).
 
     Returns dict(indices int64 [N], idx32, dmin|None, quantized|None, loss_partial|None, n_partial).
@@ -124,9 +125,13 @@ def search(z: torch.Tensor, E: torch.Tensor, ws: Workspace, temperature: float =
                                   _ptr(idx64), _ptr(idx32), _ptr(dmin), _ptr(q), _ptr(lp), s), "vq_search_exact")
     else:
         nf_rows = ws.get("nf_rows", N * 4, torch.int32)
+        if events is not None:
+            events[0].record(torch.cuda.current_stream(dev))
         check(lib.vq_search(_ptr(z), layout, N, D, HW, _ptr(E), _ptr(image), _ptr(e2), K, float(temperature),
                             code_base, _ptr(idx64), _ptr(idx32), _ptr(dmin), _ptr(q), _ptr(lp), _ptr(nf_rows),
                             _ptr(control), s), "vq_search")
+        if events is not None:
+            events[1].record(torch.cuda.current_stream(dev))
     return {"indices": idx64, "idx32": idx32, "dmin": dmin, "quantized": q, "loss_partial": lp,
             "n_partial": n_partial, "layout": layout, "N": N, "HW": HW, "control": control}
 
@@ -233,7 +238,7 @@ def gather_st(z: torch.Tensor, E: torch.Tensor, idx64: torch.Tensor, ws: Workspa
 
 def quantize_step(z: torch.Tensor, E: torch.Tensor, ema_w, cluster_size, usage, *, beta: float, decay: float,
                   epsilon: float, temperature: float, training: bool, ws: Workspace, want_dmin: bool = False,
-                  stats_reduce=None) -> StepResult:
+                  stats_reduce=None, search_events=None) -> StepResult:
     """One full forward of the quantizer: search, gather, loss, histogram, perplexity and, in
     training mode, the EMA update of (usage, cluster_size, ema_w, E) in place.
 
@@ -243,7 +248,7 @@ def quantize_step(z: torch.Tensor, E: torch.Tensor, ema_w, cluster_size, usage, 
     local-batch mean, as it would under DistributedDataParallel.
     """
     K, D = E.shape
-    r = search(z, E, ws, temperature=temperature, want_quantized=True, want_dmin=want_dmin)
+    r = search(z, E, ws, temperature=temperature, want_quantized=True, want_dmin=want_dmin, events=search_events)
     N = r["N"]
     counts = ws.get("counts", K * 4, torch.int32)
     histogram(r["idx32"][:N], K, ws, out=counts)

@@ -1,0 +1,101 @@
+"""Codebook statistics on the GPU: the maths of the reference's analysers applied to true
+code indices, without host round trips per code.
+
+* ``CodeUsage`` / ``analyze_indices``: vqvae/codebook_utilization_check.py:83-108 (float64).
+* ``batch_code_stats``: vqvae/vqgan_trainer.py:594-612 (fp32).
+* ``count_used_codes``: vqvae/trainers/vqtrainer.py:59-75 (search + number of distinct codes).
+* ``pairwise_codebook_stats``: the codebook-distance analysis the reference's README.md:26-29
+  describes (the reference holds no code for it; the definition is this package's).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+from ._lib import check, load
+
+
+class CodeUsage:
+    """Accumulates a code histogram over batches of indices, then reports the statistics of
+    analyze_codebook_utilization (vqvae/codebook_utilization_check.py:83-120)."""
+
+    def __init__(self, num_embeddings: int, device):
+        self.K = int(num_embeddings)
+        self.device = torch.device(device)
+        self.ws = ops.Workspace(self.device)
+        self.counts = torch.zeros(self.K, dtype=torch.int32, device=self.device)   # uint32 bit patterns
+        self.total = 0
+
+    def update(self, indices: torch.Tensor) -> None:
+        ops.histogram(indices, self.K, self.ws, out=self.counts, accumulate=True)
+        self.total += indices.numel()
+
+    def result(self) -> dict:
+        lib = load()
+        out = torch.empty(5, dtype=torch.float64, device=self.device)
+        check(lib.vq_index_stats(ops._ptr(self.counts), self.K, max(self.total, 1), ops._ptr(out), None,
+                                 ops._stream(self.device)), "vq_index_stats")
+        v = out.cpu().tolist()
+        counts = (self.counts.to(torch.int64) & 0xFFFFFFFF).cpu().numpy().astype("float64")
+        return {
+            "n_embed": self.K,
+            "unique_indices": counts.nonzero()[0],
+            "utilization": v[1],
+            "entropy": v[2],
+            "normalized_entropy": v[3],
+            "gini": v[4],
+            "index_counts": counts,
+            "probs": counts / max(self.total, 1),
+        }
+
+
+def analyze_indices(indices: torch.Tensor, num_embeddings: int) -> dict:
+    acc = CodeUsage(num_embeddings, indices.device)
+    acc.update(indices)
+    return acc.result()
+
+
+def batch_code_stats(indices: torch.Tensor, num_embeddings: int) -> dict:
+    """Per-batch utilisation and entropy as monitor_codebook prints them
+    (vqvae/vqgan_trainer.py:594-612), one kernel + one 16-byte copy instead of K host syncs."""
+    lib = load()
+    ws = ops.Workspace(indices.device)
+    counts = ops.histogram(indices, num_embeddings, ws)
+    out = torch.empty(4, dtype=torch.float32, device=indices.device)
+    check(lib.vq_index_stats(ops._ptr(counts), num_embeddings, indices.numel(), None, ops._ptr(out),
+                             ops._stream(indices.device)), "vq_index_stats")
+    v = out.cpu().tolist()
+    return {"unique": int(v[0]), "utilization": v[1], "entropy": v[2], "normalized_entropy": v[3]}
+
+
+def count_used_codes(latents: torch.Tensor, codebook: torch.Tensor, ws: Optional[ops.Workspace] = None) -> int:
+    """Number of distinct nearest codes of ``latents`` ((B, D, H, W) or (N, D)); what
+    VQModelTrainer.get_perplexity returns (vqvae/trainers/vqtrainer.py:59-77)."""
+    ws = ws or ops.Workspace(latents.device)
+    r = ops.search(latents.float(), codebook.float(), ws, want_quantized=False)
+    counts = ops.histogram(r["idx32"][: r["N"]], codebook.shape[0], ws)
+    return int((counts != 0).sum().item())
+
+
+def pairwise_codebook_stats(codebook: torch.Tensor, ws: Optional[ops.Workspace] = None) -> dict:
+    """Nearest-other-code distance per code and min / mean / max of all pairwise squared
+    distances ||e_i - e_j||^2 (i != j), computed by the MFMA search engine with z := E; the
+    K x K matrix is never stored."""
+    lib = load()
+    E = ops._f32c(codebook, "codebook")
+    K, D = E.shape
+    ws = ws or ops.Workspace(E.device)
+    image, e2, control = ops.prepare_codebook(E, ws)
+    blocks = lib.vq_search_blocks(K)
+    nn_dist = torch.empty(K, dtype=torch.float32, device=E.device)
+    nn_idx = torch.empty(K, dtype=torch.int64, device=E.device)
+    sum_partial = ws.get("pw_sum", blocks * 8, torch.float64)
+    mm_partial = ws.get("pw_mm", (2 * blocks + K) * 4, torch.float32)
+    out = torch.empty(3, dtype=torch.float64, device=E.device)
+    check(lib.vq_pairwise_stats(ops._ptr(E), ops._ptr(image), ops._ptr(e2), K, D, ops._ptr(nn_dist),
+                                ops._ptr(nn_idx), ops._ptr(sum_partial), ops._ptr(mm_partial), ops._ptr(out),
+                                ops._ptr(control), ops._stream(E.device)), "vq_pairwise_stats")
+    v = out.cpu().tolist()
+    return {"nn_dist": nn_dist, "nn_idx": nn_idx, "min": v[0], "mean": v[1], "max": v[2]}
