@@ -108,12 +108,17 @@ int vq_code_histogram(const void* idx, int idx_is_64, int64_t M, int K, uint32_t
 
 /*
  * EMA embedding sums: slab[s][k][c] = sum of z[n][c] over the rows n of slab s with
- * idx32[n] == k.  ref: vqvae/ema_vector_quantizer.py:84 (encodings.t() @ flat_input).
- * Writes vq_scatter_slabs(N,K,D) slabs of K*D floats; their sum over s is dw.  LDS-private
- * accumulation, one wave per channel, so the result is reproducible run to run.
+ * idx32[n] == code_base + k.  ref: vqvae/ema_vector_quantizer.py:84 (encodings.t() @ flat_input).
+ * Writes vq_scatter_slabs(N,K,D) slabs of K*D floats; their sum over s is dw.  The sums are
+ * accumulated in LDS in 64-bit fixed point scaled from max|z| (control word 3, written by
+ * vq_search for the same z; pass zmax_valid = 0 to have it computed here), so they do not
+ * depend on arrival order: bit-reproducible, each element rounded once at max|z| * 2^-40 or
+ * finer.  A batch holding NaN/inf takes a float-atomic path that propagates them like the
+ * reference.  Rows whose index falls outside [code_base, code_base + K) are skipped
+ * (codebook-row sharding: a rank accumulates only the rows its shard won).
  */
 int vq_ema_scatter(const float* z, int layout, int64_t N, int D, int64_t HW, const int32_t* idx32, int K,
-                   float* slabs, void* stream);
+                   int64_t code_base, int zmax_valid, int32_t* control, float* slabs, void* stream);
 
 /* dw[k][c] = sum_s slabs[s][k][c] in slab order (packs the data-parallel all-reduce buffer). */
 int vq_reduce_slabs(const float* slabs, int nslab, int K, int D, float* dw, void* stream);

@@ -27,7 +27,7 @@ __host__ __device__ inline size_t vq_stage_floats(int D) { return (size_t)VQ_STA
 __host__ __device__ inline bool vq_fast_dim(int D) { return D == 16 || D == 32 || D == 64 || D == 128 || D == 256; }
 
 // Control words shared by the kernels of one step (device memory, 16 ints).
-enum { VQ_CTL_NF_COUNT = 0, VQ_CTL_CB_FLAG = 1, VQ_CTL_BAD_INDEX = 2, VQ_CTL_WORDS = 16 };
+enum { VQ_CTL_NF_COUNT = 0, VQ_CTL_CB_FLAG = 1, VQ_CTL_BAD_INDEX = 2, VQ_CTL_ZMAX = 3, VQ_CTL_WORDS = 16 };
 
 static inline int vq_hip_status(hipError_t e) { return e == hipSuccess ? VQ_OK : VQ_ERR_HIP_BASE + (int)e; }
 
@@ -48,6 +48,34 @@ __device__ __forceinline__ bool vq_merge_takes(float d, int i, float best, int b
   if (vq_argmin_takes(best, d)) return false;
   // equal distances, or both NaN
   return i < bi;
+}
+
+// max |z| as the bit pattern of the absolute value (monotone for non-NaN; NaN patterns are
+// above infinity's, so a NaN anywhere makes the maximum read "not finite").  Result in
+// control word VQ_CTL_ZMAX.
+static __global__ __launch_bounds__(256) void vq_absmax_kernel(const float* __restrict__ z, int64_t numel,
+                                                               int32_t* control) {
+  uint32_t m = 0;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += stride) {
+    const uint32_t b = __float_as_uint(z[i]) & 0x7fffffffu;
+    m = b > m ? b : m;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const uint32_t o = (uint32_t)__shfl_xor((int)m, off);
+    m = o > m ? o : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(reinterpret_cast<unsigned int*>(&control[VQ_CTL_ZMAX]), m);
+}
+
+static inline int vq_launch_absmax(const float* z, int64_t numel, int32_t* control, hipStream_t s) {
+  VQ_CHECK_HIP(hipMemsetAsync(&control[VQ_CTL_ZMAX], 0, 4, s));
+  int64_t blocks = (numel + 256 * 32 - 1) / (256 * 32);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(vq_absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, z, numel, control);
+  return vq_hip_status(hipGetLastError());
 }
 
 // Internal (not in the public header): the pairwise variant of the MFMA search, z := E.

@@ -50,81 +50,172 @@ __global__ __launch_bounds__(256) void vq_hist_global_kernel(const IndexT* __res
 }
 
 // ---------------------------------------------------------------------------------------
-// Embedding sums (the scatter-add).  A workgroup owns 4 channels x one slab of rows x a
-// range of up to 8192 codes; wave w accumulates channel c0+w into its own K-float LDS
-// array with ds_add_f32.  With the NCHW layout a channel of 64 consecutive rows is 256
-// contiguous bytes, so z streams in whole lines and is read exactly once.  No two waves
-// ever touch the same LDS word and each wave walks its rows in a fixed order, so the sums
-// are reproducible.  The slab is flushed as [k][4 channels] 16-byte pieces.
+// Embedding sums (the scatter-add).  A workgroup of 8 waves owns 2 channels x one slab of
+// rows x a range of up to 8192 codes and accumulates into LDS.  With the NCHW layout a
+// channel of 64 consecutive rows is 256 contiguous bytes, so z streams in whole lines and is
+// read exactly once.
+//
+// LDS float atomics (ds_add_f32) run at well under one lane per clock on gfx950, while the
+// integer ones (ds_add_u32/u64) run at full bank rate, so the sums are kept in 64-bit
+// fixed point: every value is scaled by 2^F (F chosen from max|z| and the slab's row count
+// so that no sum can overflow), rounded once to an integer, and added with ds_add_u64.
+// Integer addition commutes exactly, so the result is independent of the order in which
+// waves and lanes arrive -- bit-reproducible -- and its error (one rounding of at most
+// max|z| * 2^-40 per element) is far below an fp32 summation's.  A batch that contains a
+// NaN or an infinity takes the float-atomic path instead, which propagates them into the
+// sums exactly as the reference's dense product does.
 // ---------------------------------------------------------------------------------------
-constexpr int SCAT_KR = 8192;     // codes per pass (4 x 8192 floats = 128 KiB of LDS)
+constexpr int SCAT_KR = 8192;     // codes per pass (2 x 8192 x 8 B = 128 KiB of LDS)
 constexpr int SCAT_MIN_ROWS = 4096;
+constexpr int SCAT_THREADS = 512;
 
 struct ScatterPlan { int nslab; int64_t rows_per_slab; };
 
 ScatterPlan scatter_plan(int64_t N, int K, int D) {
-  const int slices = (D + 3) / 4;
+  const int slices = (D + 1) / 2;
   const int kr = (K + SCAT_KR - 1) / SCAT_KR;
   int64_t want = (512 + (int64_t)slices * kr - 1) / ((int64_t)slices * kr);  // >= 512 workgroups in all
   const int64_t maxslab = (N + SCAT_MIN_ROWS - 1) / SCAT_MIN_ROWS;
   if (want > maxslab) want = maxslab;
   if (want < 1) want = 1;
   if (want > 64) want = 64;
-  // rows per slab: multiple of 256 so wave-sized runs stay aligned
+  // rows per slab: multiple of 1024 so that wave-sized runs stay aligned
   int64_t rows = (N + want - 1) / want;
-  rows = (rows + 255) / 256 * 256;
+  rows = (rows + 1023) / 1024 * 1024;
   const int nslab = (int)((N + rows - 1) / rows);
   return {nslab, rows};
 }
 
-__global__ __launch_bounds__(256) void vq_scatter_kernel(const float* __restrict__ z, int nchw, int64_t N, int D,
-                                                         int64_t HW, const int32_t* __restrict__ idx32, int K,
-                                                         int64_t rows_per_slab, float* __restrict__ slabs) {
-  extern __shared__ __attribute__((aligned(16))) float acc[];  // [4][kr_len]
+// Division of a row index (< 2^31) by the invariant HW: q = umulhi(n, M) >> sh, exact for every
+// n < 2^31 when M = floor(2^(31+s)/d) + 1 and sh = s - 1, s = ceil(log2 d)  (d >= 2).
+struct FastDiv { uint32_t d, M, sh; };
+
+FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f{d, 0u, 0u};
+  if (d <= 1) return f;
+  uint32_t s = 0;
+  while (((uint64_t)1 << s) < d) ++s;
+  f.M = (uint32_t)((((uint64_t)1 << (31 + s)) / d) + 1);
+  f.sh = s - 1;
+  return f;
+}
+
+__device__ __forceinline__ uint32_t fastdiv(uint32_t n, const FastDiv& f) {
+  return f.d <= 1 ? n : (__umulhi(n, f.M) >> f.sh);
+}
+
+__device__ __forceinline__ void scat_add(unsigned long long* acc_i, float* acc_f, bool fixed, double scale, int k,
+                                         int kr_len, float v) {
+  if ((unsigned)k < (unsigned)kr_len) {
+    if (fixed) atomicAdd(&acc_i[k], (unsigned long long)__double2ll_rn((double)v * scale));
+    else atomicAdd(&acc_f[k], v);
+  }
+}
+
+// MODE 0: row-major z.  MODE 1: NCHW, any HW.  MODE 2: NCHW with HW % 4 == 0 -- four consecutive
+// rows of one channel are 16 contiguous bytes, so every lane streams float4 / int4.
+template <int MODE>
+__global__ __launch_bounds__(SCAT_THREADS) void vq_scatter_kernel(const float* __restrict__ z, int N, int D,
+                                                                  FastDiv hwdiv, const int32_t* __restrict__ idx32,
+                                                                  int K, int code_base, int rows_per_slab,
+                                                                  const int32_t* __restrict__ control,
+                                                                  float* __restrict__ slabs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long acc_i[];  // [2][kr_len] int64, or floats
+  float* acc_f = reinterpret_cast<float*>(acc_i);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c0 = blockIdx.x * 4;
+  const int c0 = blockIdx.x * 2;
   const int slab = blockIdx.y;
   const int k0 = blockIdx.z * SCAT_KR;
   const int kr_len = (K - k0) < SCAT_KR ? (K - k0) : SCAT_KR;
-  for (int i = threadIdx.x; i < 4 * kr_len; i += 256) acc[i] = 0.0f;
+  for (int i = threadIdx.x; i < 2 * kr_len; i += SCAT_THREADS) acc_i[i] = 0ull;
+
+  // fixed-point scale: max|z| < 2^e, at most 2^r rows per slab  =>  |sum| * 2^F < 2^62
+  const uint32_t zmax_bits = (uint32_t)control[VQ_CTL_ZMAX];
+  // 0 = unknown (or an all-zero batch): the float path is always valid
+  const bool fixed = zmax_bits != 0 && zmax_bits < 0x7f800000u;
+  int F = 0;
+  if (fixed) {
+    int e;
+    (void)frexpf(__uint_as_float(zmax_bits), &e);  // zmax = m * 2^e, m in [0.5, 1)
+    const int r = 32 - __clz((unsigned)(rows_per_slab > 1 ? rows_per_slab - 1 : 1));
+    F = 62 - e - r;
+  }
+  const double scale = ldexp(1.0, F), inv_scale = ldexp(1.0, -F);
   __syncthreads();
 
-  const int c = c0 + wave;
-  const int64_t n_begin = (int64_t)slab * rows_per_slab;
-  const int64_t n_end = (n_begin + rows_per_slab) < N ? (n_begin + rows_per_slab) : N;
-  float* mine = acc + (size_t)wave * kr_len;
+  const int chsel = wave >> 2, sub = wave & 3;   // 4 waves per channel share the rows of the slab
+  const int c = c0 + chsel;
+  const int n_begin = slab * rows_per_slab;
+  const int n_end = (N - n_begin) < rows_per_slab ? N : n_begin + rows_per_slab;
+  unsigned long long* mine_i = acc_i + (size_t)chsel * kr_len;
+  float* mine_f = acc_f + (size_t)chsel * kr_len;
+  const int kbase = code_base + k0;
+  const int HW = (int)hwdiv.d;
   if (c < D) {
-    constexpr int U = 8;  // independent loads in flight per lane
-    for (int64_t n0 = n_begin + lane; n0 < n_end; n0 += 64 * U) {
-      float v[U];
-      int k[U];
+    if (MODE == 2) {
+      constexpr int U = 4;  // 4 x 16 B of z and of indices in flight per lane, 8 waves per CU
+      for (int n0 = n_begin + 4 * lane + 256 * sub; n0 < n_end; n0 += 1024 * U) {
+        f32x4 v[U];
+        int4 k[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int64_t n = n0 + 64 * u;
-        const bool in = n < n_end;
-        const int64_t nn = in ? n : n_begin;
-        int64_t off;
-        if (nchw) { const int64_t b = nn / HW, hw = nn - b * HW; off = (b * D + c) * HW + hw; }
-        else off = nn * D + c;
-        v[u] = z[off];
-        k[u] = in ? idx32[nn] - k0 : -1;
+        for (int u = 0; u < U; ++u) {
+          const int n = n0 + 1024 * u;
+          const bool in = n < n_end;             // n_end, n_begin and n are multiples of 4 here
+          const int nn = in ? n : n_begin;
+          const uint32_t b = fastdiv((uint32_t)nn, hwdiv);
+          const size_t off = ((size_t)b * D + c) * HW + (nn - (int)b * HW);
+          v[u] = *reinterpret_cast<const f32x4*>(z + off);
+          k[u] = *reinterpret_cast<const int4*>(idx32 + nn);
+          if (!in) k[u] = int4{kbase - 1, kbase - 1, kbase - 1, kbase - 1};
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          scat_add(mine_i, mine_f, fixed, scale, k[u].x - kbase, kr_len, v[u][0]);
+          scat_add(mine_i, mine_f, fixed, scale, k[u].y - kbase, kr_len, v[u][1]);
+          scat_add(mine_i, mine_f, fixed, scale, k[u].z - kbase, kr_len, v[u][2]);
+          scat_add(mine_i, mine_f, fixed, scale, k[u].w - kbase, kr_len, v[u][3]);
+        }
       }
+    } else {
+      constexpr int U = 8;
+      for (int n0 = n_begin + lane + 64 * sub; n0 < n_end; n0 += 256 * U) {
+        float v[U];
+        int k[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (k[u] >= 0 && k[u] < kr_len) atomicAdd(&mine[k[u]], v[u]);
+        for (int u = 0; u < U; ++u) {
+          const int n = n0 + 256 * u;
+          const bool in = n < n_end;
+          const int nn = in ? n : n_begin;
+          size_t off;
+          if (MODE == 1) {
+            const uint32_t b = fastdiv((uint32_t)nn, hwdiv);
+            off = ((size_t)b * D + c) * HW + (nn - (int)b * HW);
+          } else {
+            off = (size_t)nn * D + c;
+          }
+          v[u] = z[off];
+          k[u] = in ? idx32[nn] - kbase : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) scat_add(mine_i, mine_f, fixed, scale, k[u], kr_len, v[u]);
+      }
     }
   }
   __syncthreads();
-  // flush: slab[k][c0..c0+3]
+  // flush: slab[k][c0], slab[k][c0+1]
   float* out = slabs + (size_t)slab * K * D;
-  for (int kk = threadIdx.x; kk < kr_len; kk += 256) {
-    float* dst = out + (size_t)(k0 + kk) * D + c0;
-    if (c0 + 3 < D && (D & 3) == 0) {
-      *reinterpret_cast<f32x4*>(dst) = f32x4{acc[kk], acc[kr_len + kk], acc[2 * kr_len + kk], acc[3 * kr_len + kk]};
+  for (int kk = threadIdx.x; kk < kr_len; kk += SCAT_THREADS) {
+    float s0, s1;
+    if (fixed) {
+      s0 = (float)((double)(long long)acc_i[kk] * inv_scale);
+      s1 = (float)((double)(long long)acc_i[kr_len + kk] * inv_scale);
     } else {
-      for (int w = 0; w < 4; ++w)
-        if (c0 + w < D) dst[w] = acc[(size_t)w * kr_len + kk];
+      s0 = acc_f[kk];
+      s1 = acc_f[kr_len + kk];
     }
+    float* dst = out + (size_t)(k0 + kk) * D + c0;
+    dst[0] = s0;
+    if (c0 + 1 < D) dst[1] = s1;
   }
 }
 
@@ -294,25 +385,45 @@ int vq_code_histogram(const void* idx, int idx_is_64, int64_t M, int K, uint32_t
 }
 
 int vq_ema_scatter(const float* z, int layout, int64_t N, int D, int64_t HW, const int32_t* idx32, int K,
-                   float* slabs, void* stream) {
-  if (!z || !idx32 || !slabs || N <= 0 || K <= 0 || D <= 0) return VQ_ERR_INVALID_ARG;
+                   int64_t code_base, int zmax_valid, int32_t* control, float* slabs, void* stream) {
+  if (!z || !idx32 || !slabs || !control || N <= 0 || K <= 0 || D <= 0) return VQ_ERR_INVALID_ARG;
   if (layout != VQ_LAYOUT_ND && layout != VQ_LAYOUT_NCHW) return VQ_ERR_INVALID_ARG;
   if (layout == VQ_LAYOUT_NCHW && (HW <= 0 || N % HW != 0)) return VQ_ERR_INVALID_ARG;
+  if (N >= ((int64_t)1 << 31) || code_base < 0 || code_base + K >= ((int64_t)1 << 31)) return VQ_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (!zmax_valid) {
+    int rc = vq_launch_absmax(z, N * D, control, s);
+    if (rc != VQ_OK) return rc;
+  }
   const ScatterPlan p = scatter_plan(N, K, D);
   const int kr = (K + SCAT_KR - 1) / SCAT_KR;
   const int kr_len = K < SCAT_KR ? K : SCAT_KR;
-  const size_t lds = (size_t)4 * kr_len * 4;
-  static bool attr_done[64] = {};
+  const size_t lds = (size_t)2 * kr_len * 8;
+  const bool nchw = layout == VQ_LAYOUT_NCHW && HW > 1;
+  const bool vec4 = nchw && (HW % 4 == 0) && ((reinterpret_cast<uintptr_t>(z) & 15) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(idx32) & 15) == 0);
+  const int mode = vec4 ? 2 : (nchw ? 1 : 0);
+  const void* kern = mode == 2 ? reinterpret_cast<const void*>(vq_scatter_kernel<2>)
+                   : mode == 1 ? reinterpret_cast<const void*>(vq_scatter_kernel<1>)
+                               : reinterpret_cast<const void*>(vq_scatter_kernel<0>);
+  static bool attr_done[3][64] = {};
   int dev = 0;
   VQ_CHECK_HIP(hipGetDevice(&dev));
-  if (!attr_done[dev & 63]) {
-    VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vq_scatter_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SCAT_KR * 4));
-    attr_done[dev & 63] = true;
+  if (!attr_done[mode][dev & 63]) {
+    VQ_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SCAT_KR * 8));
+    attr_done[mode][dev & 63] = true;
   }
-  hipLaunchKernelGGL(vq_scatter_kernel, dim3((D + 3) / 4, p.nslab, kr), dim3(256), lds, (hipStream_t)stream, z,
-                     layout == VQ_LAYOUT_NCHW ? 1 : 0, N, D, layout == VQ_LAYOUT_NCHW ? HW : 1, idx32, K,
-                     p.rows_per_slab, slabs);
+  const FastDiv fd = make_fastdiv(nchw ? (uint32_t)HW : 1u);
+  const dim3 grid((D + 1) / 2, p.nslab, kr);
+  if (mode == 2)
+    hipLaunchKernelGGL(vq_scatter_kernel<2>, grid, dim3(SCAT_THREADS), lds, s, z, (int)N, D, fd, idx32, K,
+                       (int)code_base, (int)p.rows_per_slab, control, slabs);
+  else if (mode == 1)
+    hipLaunchKernelGGL(vq_scatter_kernel<1>, grid, dim3(SCAT_THREADS), lds, s, z, (int)N, D, fd, idx32, K,
+                       (int)code_base, (int)p.rows_per_slab, control, slabs);
+  else
+    hipLaunchKernelGGL(vq_scatter_kernel<0>, grid, dim3(SCAT_THREADS), lds, s, z, (int)N, D, fd, idx32, K,
+                       (int)code_base, (int)p.rows_per_slab, control, slabs);
   return vq_hip_status(hipGetLastError());
 }
 

@@ -138,6 +138,7 @@ __global__ __launch_bounds__(256, 1) void vq_search_mfma_kernel(SearchArgs a) {
   float z2[2];
   int64_t zoff[2];            // element offset of this lane's first channel of the row
   int64_t zstride = 2 * a.HW;  // NCHW: elements between channels 2s+h and 2s+2+h
+  uint32_t zmax_bits = 0;      // max |z| of this lane's values (bit pattern), for the EMA scatter's scaling
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) {
     int64_t n = row0 + ct * 32 + j;
@@ -159,14 +160,28 @@ __global__ __launch_bounds__(256, 1) void vq_search_mfma_kernel(SearchArgs a) {
         zr[ct][2 * m + 1] = h ? v[3] : v[2];
       }
     }
+    uint32_t am = 0;
 #pragma unroll
-    for (int s = 0; s < S; ++s) p = __builtin_fmaf(zr[ct][s], zr[ct][s], p);
+    for (int s = 0; s < S; ++s) {
+      p = __builtin_fmaf(zr[ct][s], zr[ct][s], p);
+      const uint32_t ab = __float_as_uint(zr[ct][s]) & 0x7fffffffu;
+      am = ab > am ? ab : am;
+    }
+    zmax_bits = am > zmax_bits ? am : zmax_bits;
     z2[ct] = p + __shfl_xor(p, 32);  // even-channel chain + odd-channel chain
     // Cut the address expressions of the loads off from those of the stores after the
     // sweep: otherwise the compiler keeps 128 store addresses alive through the MFMA loop.
     asm volatile("" : "+v"(zoff[ct]));
   }
   asm volatile("" : "+s"(zstride));
+  if (!PAIRWISE) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const uint32_t o = (uint32_t)__shfl_xor((int)zmax_bits, off);
+      zmax_bits = o > zmax_bits ? o : zmax_bits;
+    }
+    if (lane == 0 && zmax_bits) atomicMax(reinterpret_cast<unsigned int*>(&a.control[VQ_CTL_ZMAX]), zmax_bits);
+  }
 
   float best[2] = {__builtin_inff(), __builtin_inff()};
   int bidx[2] = {0, 0};
@@ -712,6 +727,10 @@ static int search_common(const float* z, int layout, int64_t N, int D, int64_t H
   }
   // exact path for everything: partials [0, blocks) are zeroed, the kernel fills the tail
   if (loss_partial) VQ_CHECK_HIP(hipMemsetAsync(loss_partial, 0, (size_t)blocks * 4, s));
+  if (control) {
+    int rc = vq_launch_absmax(z, N * D, control, s);
+    if (rc != VQ_OK) return rc;
+  }
   float* fix_loss = loss_partial ? loss_partial + blocks : nullptr;
   return run_exact(a, D, nchw, false, fix_loss, VQ_FIX_WGS, s);
 }

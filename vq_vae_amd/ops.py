@@ -133,7 +133,8 @@ def search(z: torch.Tensor, E: torch.Tensor, ws: Workspace, temperature: float =
         if events is not None:
             events[1].record(torch.cuda.current_stream(dev))
     return {"indices": idx64, "idx32": idx32, "dmin": dmin, "quantized": q, "loss_partial": lp,
-            "n_partial": n_partial, "layout": layout, "N": N, "HW": HW, "control": control}
+            "n_partial": n_partial, "layout": layout, "N": N, "HW": HW, "control": control,
+            "zmax_valid": not exact}
 
 
 def histogram(idx: torch.Tensor, K: int, ws: Workspace, out: Optional[torch.Tensor] = None,
@@ -151,16 +152,19 @@ def histogram(idx: torch.Tensor, K: int, ws: Workspace, out: Optional[torch.Tens
     return counts
 
 
-def embed_sums(z: torch.Tensor, idx32: torch.Tensor, K: int, ws: Workspace):
-    """vq_ema_scatter: returns (slabs [nslab, K, D], nslab)."""
+def embed_sums(z: torch.Tensor, idx32: torch.Tensor, K: int, ws: Workspace, code_base: int = 0,
+               zmax_valid: bool = False):
+    """vq_ema_scatter: returns (slabs [nslab, K, D], nslab).  ``zmax_valid`` says that a search over the
+    same ``z`` has just left max|z| in the workspace's control block."""
     lib = _lib.load()
     z = _f32c(z, "latents")
     D = z.shape[1]
     layout, N, HW = _shape_of(z, D)
     nslab = lib.vq_scatter_slabs(N, K, D)
     slabs = ws.get("slabs", nslab * K * D * 4, torch.float32)[: nslab * K * D].view(nslab, K, D)
-    check(lib.vq_ema_scatter(_ptr(z), layout, N, D, HW, _ptr(idx32), K, _ptr(slabs), _stream(z.device)),
-          "vq_ema_scatter")
+    control = ws.get("control", lib.vq_control_bytes(), torch.int32)
+    check(lib.vq_ema_scatter(_ptr(z), layout, N, D, HW, _ptr(idx32), K, code_base, 1 if zmax_valid else 0,
+                             _ptr(control), _ptr(slabs), _stream(z.device)), "vq_ema_scatter")
     return slabs, nslab
 
 
@@ -256,12 +260,12 @@ def quantize_step(z: torch.Tensor, E: torch.Tensor, ema_w, cluster_size, usage, 
                                  counts if stats_reduce is None else None, K, z.device)
     if stats_reduce is None:
         if training:
-            slabs, _ = embed_sums(_f32c(z, "latents"), r["idx32"], K, ws)
+            slabs, _ = embed_sums(_f32c(z, "latents"), r["idx32"], K, ws, zmax_valid=r["zmax_valid"])
             ema_update(counts, slabs, usage, cluster_size, ema_w, E, decay, epsilon)
     else:
         dw = None
         if training:
-            slabs, _ = embed_sums(_f32c(z, "latents"), r["idx32"], K, ws)
+            slabs, _ = embed_sums(_f32c(z, "latents"), r["idx32"], K, ws, zmax_valid=r["zmax_valid"])
             dw = reduce_slabs(slabs, out=ws.get("dw", K * D * 4, torch.float32)[: K * D].view(K, D))
         counts64, dw, n_total = stats_reduce(counts, dw, N)
         # perplexity and the EMA update come from the reduced statistics, so every rank computes
