@@ -1,0 +1,128 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol the header declares, the
+host-only size helpers behave, and the drop-in module keeps the reference's interface.  No
+compute call is made here (there is no GPU in this environment)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "vq_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vq_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_entry_points():
+    syms = header_symbols()
+    for must in ("vq_search", "vq_codebook_prep", "vq_ema_scatter", "vq_ema_cluster_update",
+                 "vq_ema_codebook_update", "vq_code_histogram", "vq_pairwise_stats", "vq_index_stats"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from vq_vae_amd import _lib
+    lib = _lib.load()
+    for s in header_symbols():
+        assert hasattr(lib, s), f"libvqhip.so lacks {s}"
+    assert set(header_symbols()) == set(_lib.SIGNATURES), "ctypes signature table and header disagree"
+    assert lib.vq_version() >= 100
+
+
+def test_size_helpers():
+    from vq_vae_amd import _lib
+    lib = _lib.load()
+    # image: one stage per 64 codes, 64*D floats + a 1 KiB norms piece
+    assert lib.vq_image_bytes(8192, 256) == 128 * (64 * 256 + 256) * 4
+    assert lib.vq_image_bytes(100, 32) == 2 * (64 * 32 + 256) * 4
+    assert lib.vq_norms_bytes(100) == 128 * 4
+    assert lib.vq_search_blocks(4194304) == 16384 and lib.vq_search_blocks(1) == 1
+    assert lib.vq_loss_partial_bytes(4096) == (16 + 1024) * 4
+    assert lib.vq_scatter_slabs(4194304, 8192, 256) >= 4
+    assert lib.vq_scatter_slabs(128, 512, 64) == 1
+    assert lib.vq_status_string(0) == b"ok"
+    assert lib.vq_status_string(1) == b"invalid argument"
+
+
+def test_entry_points_reject_bad_arguments_without_a_gpu():
+    from vq_vae_amd import _lib
+    lib = _lib.load()
+    # argument validation happens before any HIP call
+    assert lib.vq_codebook_prep(None, 512, 64, None, None, None, None) == 1
+    assert lib.vq_search(None, 1, 128, 64, 64, None, None, None, 512, 1.0, 0, None, None, None, None, None, None,
+                         None, None) == 1
+    assert lib.vq_code_histogram(None, 0, 10, 512, None, 0, None, None) == 1
+    assert lib.vq_ema_scatter(None, 1, 128, 64, 64, None, 512, 0, 0, None, None, None) == 1
+
+
+def test_module_interface_matches_reference():
+    from vq_vae_amd import EMAVectorQuantizer
+    m = EMAVectorQuantizer(num_embeddings=512, embedding_dim=64, commitment_cost=3.0, decay=0.95)
+    sd = m.state_dict()
+    # names, order, shapes, dtypes of vqvae/ema_vector_quantizer.py:21-31
+    assert list(sd.keys()) == ["ema_cluster_size", "ema_w", "usage_count", "last_reset_epoch",
+                               "last_low_usage_reset_epoch", "embedding.weight"]
+    assert sd["ema_cluster_size"].shape == (512,) and sd["ema_w"].shape == (512, 64)
+    assert sd["usage_count"].shape == (512,) and sd["last_reset_epoch"].shape == (1,)
+    assert sd["embedding.weight"].shape == (512, 64)
+    assert all(v.dtype == torch.float32 for v in sd.values())
+    assert float(sd["ema_w"].abs().sum()) == 0.0                       # zeros, not a copy of the codebook
+    w = sd["embedding.weight"]
+    assert float(w.abs().max()) <= 1.0 / 512 and float(w.abs().max()) > 0  # U(-1/K, 1/K)
+    assert [n for n, _ in m.named_parameters()] == ["embedding.weight"]
+    assert m.embedding.weight.requires_grad
+    assert (m.num_embeddings, m.embedding_dim, m.commitment_cost, m.decay, m.epsilon) == (512, 64, 3.0, 0.95, 1e-5)
+    for meth in ("expand_codebook", "reset_dead_codes", "get_codebook_stats", "reset_low_usage_codes"):
+        assert callable(getattr(m, meth))
+    # strict round trip through a second instance
+    m2 = EMAVectorQuantizer(512, 64, 3.0)
+    m2.load_state_dict(sd, strict=True)
+    assert torch.equal(m2.embedding.weight, m.embedding.weight)
+    # maintenance methods return early exactly like the reference when not training / no epoch
+    m.eval()
+    assert m.reset_dead_codes(current_epoch=10) == 0 and m.reset_low_usage_codes(current_epoch=10) == 0
+    m.train()
+    assert m.reset_dead_codes(current_epoch=None) == 0
+    assert m.expand_codebook(512) is False
+
+
+def test_module_refuses_cpu_tensors():
+    from vq_vae_amd import EMAVectorQuantizer
+    m = EMAVectorQuantizer(512, 64, 3.0)
+    with pytest.raises(RuntimeError, match="only on the GPU"):
+        m(torch.randn(2, 64, 4, 4))
+
+
+def test_expand_codebook_on_cpu_state():
+    """expand_codebook is pure state surgery (vqvae/ema_vector_quantizer.py:110-163): old rows kept,
+    EMA buffers zero-extended, state_dict still has the six entries."""
+    from vq_vae_amd import EMAVectorQuantizer
+    torch.manual_seed(0)
+    m = EMAVectorQuantizer(64, 16, 3.0)
+    m.usage_count[:8] = torch.arange(8, 0, -1).float()
+    m.ema_cluster_size[:] = 1.5
+    old = m.embedding.weight.detach().clone()
+    assert m.expand_codebook(80) is True
+    assert m.num_embeddings == 80 and m.embedding.weight.shape == (80, 16)
+    assert torch.equal(m.embedding.weight[:64], old)
+    assert m.ema_cluster_size.shape == (80,) and float(m.ema_cluster_size[64:].abs().sum()) == 0.0
+    assert m.ema_w.shape == (80, 16) and m.usage_count.shape == (80,)
+    assert len(m.state_dict()) == 6
+
+
+def test_ema_scalars_round_like_the_reference_expressions():
+    from vq_vae_amd.ops import ema_scalars
+    d, omd, eps, keps = ema_scalars(8192, 0.95, 1e-5)
+    assert d == float(np.float32(0.95)) and omd == float(np.float32(1 - 0.95))
+    assert eps == float(np.float32(1e-5)) and keps == float(np.float32(8192 * 1e-5))
+
+
+def test_lazy_onehot_metadata():
+    from vq_vae_amd import LazyOneHot
+    lo = LazyOneHot(torch.tensor([3, 1, 2]), 8)
+    assert lo.shape == (3, 8) and lo.dtype == torch.float32 and lo.dim() == 2 and lo.size(1) == 8

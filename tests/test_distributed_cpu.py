@@ -1,0 +1,148 @@
+"""Multi-rank host logic on CPU (gloo, world_size 2), plus the algebra of both sharding modes
+checked against the unsharded oracle in one process.
+
+Data-parallel mode: per-rank statistics (counts, dw) summed before the EMA update must equal
+the statistics of the whole batch.  Codebook-row sharding: per-shard (distance, index) winners
+merged by the packed-key MIN must equal the unsharded argmin, ties and NaN included.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from inputs import gauss
+from oracle import vq_oracle as vo
+
+
+def pack_key(d: np.ndarray, idx: np.ndarray) -> np.ndarray:
+    """NumPy statement of the packed (distance, index) key of vq_pack_dist_index: NaN first,
+    then ascending distance, then ascending index, as a signed int64."""
+    d = np.where(d == 0, np.float32(0.0), d).astype(np.float32)      # -0.0 and +0.0 share a key
+    u = d.view(np.uint32).astype(np.uint64)
+    key = np.where(u & 0x80000000, (~u) & 0xFFFFFFFF, u | 0x80000000)
+    key = np.where(np.isnan(d), 0, key).astype(np.uint64)
+    packed = (key << np.uint64(32)) | idx.astype(np.uint64)
+    return (packed ^ np.uint64(0x8000000000000000)).view(np.int64)
+
+
+def unpack_index(p: np.ndarray) -> np.ndarray:
+    return ((p.view(np.uint64) ^ np.uint64(0x8000000000000000)) & np.uint64(0xFFFFFFFF)).astype(np.int64)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _dp_worker(rank, world, port, K, D, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vq_vae_amd.distributed import make_stats_reduce, merge_packed_winners, shard_rows
+    E = gauss(2, (K, D)) * np.float32(0.7)
+    z = gauss(10 + rank, (2, D, 8, 8))                       # this rank's rows
+    idx, _ = vo.search(z, E)
+    counts = vo.histogram(idx, K)
+    dw = vo.embed_sum(z, idx, K)
+    # the histogram kernel hands over uint32 bit patterns in an int32 tensor
+    c_i32 = torch.from_numpy(counts.astype(np.uint32).view(np.int32).copy())
+    red = make_stats_reduce()
+    c64, dw_sum, n_total = red(c_i32, torch.from_numpy(dw.copy()), z.size // D)
+    red_uneven = make_stats_reduce(uneven_rows=True)
+    c64b, _, n_total_b = red_uneven(c_i32, None, z.size // D)
+    # codebook-row sharding: this rank searches all rows of both batches against its shard
+    zall = np.concatenate([gauss(10 + r, (2, D, 8, 8)) for r in range(world)], 0)
+    lo, hi = shard_rows(K, rank, world)
+    sidx, sd = vo.search(zall, E[lo:hi], code_base=lo)
+    packed = torch.from_numpy(pack_key(sd, sidx).copy())
+    merge_packed_winners(packed)
+    q.put((rank, c64.numpy(), dw_sum.numpy(), n_total, c64b.numpy(), n_total_b, unpack_index(packed.numpy())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_and_row_sharded_over_gloo():
+    K, D, world = 128, 32, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, K, D, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    E = gauss(2, (K, D)) * np.float32(0.7)
+    zall = np.concatenate([gauss(10 + r, (2, D, 8, 8)) for r in range(world)], 0)
+    idx, _ = vo.search(zall, E)
+    counts = vo.histogram(idx, K)
+    dw = vo.embed_sum(zall, idx, K)
+    for rank, c64, dw_sum, n_total, c64b, n_total_b, merged_idx in res:
+        assert np.array_equal(c64, counts) and np.array_equal(c64b, counts)
+        assert n_total == zall.size // D and n_total_b == n_total
+        assert np.max(np.abs(dw_sum - dw)) <= 1e-5 * np.max(np.abs(dw))
+        assert np.array_equal(merged_idx, idx), "row-sharded winners differ from the unsharded argmin"
+    # every rank holds identical reduced statistics -> identical updates without a broadcast
+    assert np.array_equal(res[0][2].view(np.uint32), res[1][2].view(np.uint32))
+
+
+def test_dp_update_equals_unsharded_update():
+    """Algebra of the data-parallel step in one process: 8 row chunks -> per-chunk statistics ->
+    sum -> one EMA update == the unsharded oracle step."""
+    K, D = 256, 32
+    E = gauss(3, (K, D)) * np.float32(0.7)
+    z = gauss(4, (16, D, 8, 8))
+    full = vo.OracleState.fresh(E)
+    vo.forward(z, full, 3.0, 0.95, 1e-5, 1.0, True)
+    counts = np.zeros(K, np.int64)
+    dw = np.zeros((K, D), np.float32)
+    for chunk in np.split(z, 8, axis=0):
+        idx, _ = vo.search(chunk, E)
+        counts += vo.histogram(idx, K)
+        dw += vo.embed_sum(chunk, idx, K)
+    st = vo.OracleState.fresh(E)
+    vo.ema_update(counts, dw, st.usage_count, st.ema_cluster_size, st.ema_w, st.embedding, 0.95, 1e-5)
+    assert np.array_equal(st.usage_count, full.usage_count)
+    assert np.max(np.abs(st.ema_cluster_size - full.ema_cluster_size)) <= 1e-6 * np.max(full.ema_cluster_size)
+    assert np.max(np.abs(st.embedding - full.embedding)) <= 1e-5 * np.max(np.abs(full.embedding))
+
+
+def test_row_shard_merge_matches_unsharded_argmin():
+    """8 codebook shards, packed-key MIN merge; engineered ties, NaN rows and negative distances."""
+    K, D = 512, 16
+    E = gauss(5, (K, D))
+    E[300] = E[17]                                   # duplicate rows in different shards: lowest index must win
+    E[450] = E[17]
+    z = gauss(6, (300, D))
+    z[:8] = E[17] + np.float32(0.0)                  # exact hits on the duplicated code
+    z[9, 3] = np.nan
+    idx, dmin = vo.search(z, E)
+    merged = None
+    for r in range(8):
+        lo, hi = r * 64, (r + 1) * 64
+        sidx, sd = vo.search(z, E[lo:hi], code_base=lo)
+        p = pack_key(sd, sidx)
+        merged = p if merged is None else np.minimum(merged, p)
+    assert np.array_equal(unpack_index(merged), idx)
+    assert (idx[:8] == 17).all()
+    # ordering of the key itself
+    d = np.array([np.nan, -np.inf, -3.0, -0.0, 0.0, 1e-30, 2.5, np.inf], np.float32)
+    keys = pack_key(d, np.zeros(8, np.int64))
+    assert keys[0] == keys.min() and np.all(keys[:-1] <= keys[1:]) and keys[3] == keys[4]
+    assert pack_key(np.array([1.0], np.float32), np.array([5]))[0] < pack_key(np.array([1.0], np.float32), np.array([6]))[0]
+
+
+def test_shard_rows_cover_the_codebook():
+    from vq_vae_amd.distributed import shard_rows
+    for K, world in ((65536, 8), (100, 8), (7, 8)):
+        spans = [shard_rows(K, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == K
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))

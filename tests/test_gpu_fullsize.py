@@ -1,0 +1,57 @@
+"""BASELINE config 2 at full size (K=8192, D=256, 4 Mi latent vectors) through size-independent
+properties, plus an oracle spot check on a random sample of rows."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vq_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+
+def test_full_size_properties():
+    assert torch.cuda.is_available()
+    from vq_vae_amd import ops
+    dev = torch.device("cuda:0")
+    K, D, B, H = 8192, 256, 4096, 32
+    N = B * H * H
+    z = torch.randn(B, D, H, H, device=dev, generator=torch.Generator(device=dev).manual_seed(0))
+    E0 = torch.randn(K, D, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    E = E0.clone()
+    ema_w = torch.zeros(K, D, device=dev); cs = torch.zeros(K, device=dev); usage = torch.zeros(K, device=dev)
+    ws = ops.Workspace(dev)
+    out = ops.quantize_step(z, E, ema_w, cs, usage, beta=3.0, decay=0.95, epsilon=1e-5, temperature=1.0,
+                            training=True, ws=ws, want_dmin=True)
+    torch.cuda.synchronize()
+    idx = out.indices
+    # indices in range; histogram is a partition of the rows; usage_count took the same counts
+    assert int(idx.min()) >= 0 and int(idx.max()) < K
+    counts = (out.counts.to(torch.int64) & 0xFFFFFFFF)
+    assert int(counts.sum()) == N and torch.equal(counts, torch.bincount(idx, minlength=K))
+    assert torch.equal(usage, counts.float())
+    # checksum of the embedding sums: sum_k dw[k] == sum_n z[n]  (linearity of the scatter-add)
+    dw = ema_w / np.float32(1 - 0.95)                       # first step: ema_w = 0.05 * dw
+    col = z.double().sum(dim=(0, 2, 3)).cpu().numpy()
+    got = dw.double().sum(0).cpu().numpy()
+    assert np.max(np.abs(got - col)) <= 1e-5 * np.max(np.abs(dw.double().abs().sum(0).cpu().numpy()))
+    # quantized rows are codebook rows: re-quantizing them is the identity with zero loss
+    q = out.quantized
+    again = ops.search(q, E0, ws, want_quantized=True, want_dmin=True)
+    assert torch.equal(again["indices"], idx)
+    assert float(again["loss_partial"][: again["n_partial"]].double().sum()) <= 1e-6 * N
+    # the winner is no farther than 4096 other random codes for a sample of rows (float64 check)
+    g = torch.Generator(device=dev).manual_seed(2)
+    rows = torch.randint(0, N, (4096,), device=dev, generator=g)
+    flat = z.permute(0, 2, 3, 1).reshape(N, D)[rows]
+    win = ((flat.double() - E0[idx[rows]].double()) ** 2).sum(1)
+    other = ((flat.double() - E0[torch.randint(0, K, (4096,), device=dev, generator=g)].double()) ** 2).sum(1)
+    assert bool((win <= other * (1 + 1e-6)).all())
+    # oracle spot check: 2048 sampled rows, indices and distances bit-exact
+    sample = flat[:2048].cpu().numpy()
+    o_idx, o_d = vo.search(sample, E0.cpu().numpy())
+    assert np.array_equal(idx[rows[:2048]].cpu().numpy(), o_idx)
+    assert np.array_equal(out.dmin[rows[:2048]].cpu().numpy().view(np.uint32), o_d.view(np.uint32))
+    # every replica of a second identical run lands on the same bits (reproducible EMA update)
+    E2 = E0.clone(); w2 = torch.zeros_like(ema_w); c2 = torch.zeros_like(cs); u2 = torch.zeros_like(usage)
+    ops.quantize_step(z, E2, w2, c2, u2, beta=3.0, decay=0.95, epsilon=1e-5, temperature=1.0, training=True, ws=ws)
+    assert torch.equal(E2, E) and torch.equal(w2, ema_w) and torch.equal(c2, cs)

@@ -1,0 +1,181 @@
+"""GPU tests of the drop-in EMAVectorQuantizer module against the reference's golden outputs."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, rel_err
+from inputs import gauss
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def make(K, D, beta, decay, E, dev):
+    from vq_vae_amd import EMAVectorQuantizer
+    m = EMAVectorQuantizer(num_embeddings=K, embedding_dim=D, commitment_cost=beta, decay=decay).to(dev)
+    with torch.no_grad():
+        m.embedding.weight.copy_(torch.from_numpy(E))
+    return m
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "g1_*.npz"))))
+def test_forward_matches_reference_outputs(path, dev):
+    g = np.load(path)
+    K, D = g["E"].shape
+    z = gauss(int(g["z_seed"]), g["quantized"].shape)
+    m = make(K, D, float(g["beta"]), float(g["decay"]), g["E"], dev)
+    m.train(bool(g["training"]))
+    q, loss, (perp, idx, enc) = m(torch.from_numpy(z).to(dev), temperature=float(g["T"]))
+    # tuple layout of vqvae/ema_vector_quantizer.py:108
+    assert q.shape == z.shape and loss.dim() == 0 and perp.dim() == 0
+    assert idx.shape == (z.size // D, 1) and idx.dtype == torch.int64
+    assert enc.shape == (z.size // D, K) and enc.dtype == torch.float32
+    assert np.array_equal(idx.cpu().numpy(), g["indices"])
+    assert torch.equal(enc.argmax(1, keepdim=True), idx) and float(enc.sum()) == z.size // D
+    assert rel_err(q.detach().cpu().numpy(), g["quantized"]) <= TOL
+    assert abs(loss.item() - g["loss"]) <= TOL * abs(g["loss"])
+    assert abs(perp.item() - g["perplexity"]) <= TOL * abs(g["perplexity"])
+    sd = m.state_dict()
+    assert list(sd.keys()) == ["ema_cluster_size", "ema_w", "usage_count", "last_reset_epoch",
+                               "last_low_usage_reset_epoch", "embedding.weight"]
+    for key in sd:
+        ref = g["state_" + key.replace(".", "_")]
+        assert rel_err(sd[key].cpu().numpy(), ref) <= TOL, key
+    s = m.get_codebook_stats()
+    ref = g["stats"]
+    assert s["active_size"] == int(ref[0]) and abs(s["utilization"] - ref[1]) < 1e-12
+    assert abs(s["entropy"] - ref[2]) <= 1e-5 * max(abs(ref[2]), 1e-3)
+    assert abs(s["normalized_entropy"] - ref[3]) <= 1e-5 * max(abs(ref[3]), 1e-3)
+    assert abs(s["total_usage"] - ref[4]) <= 1e-6 * max(abs(ref[4]), 1.0)
+    assert isinstance(s["active_size"], int) and isinstance(s["entropy"], (int, float))
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "g2_*.npz"))))
+def test_training_trajectory_matches_reference(path, dev):
+    g = np.load(path)
+    K, D = g["E0"].shape
+    m = make(K, D, float(g["beta"]), float(g["decay"]), g["E0"], dev)
+    m.train()
+    for step, seed in enumerate(g["z_seeds"]):
+        z = gauss(int(seed), (4, D, 8, 8))
+        q, loss, (perp, idx, _) = m(torch.from_numpy(z).to(dev), temperature=float(g["T"]))
+        assert np.array_equal(idx.cpu().numpy(), g[f"s{step}_indices"]), f"step {step}"
+        assert abs(loss.item() - g[f"s{step}_loss"]) <= TOL * abs(g[f"s{step}_loss"])
+        assert abs(perp.item() - g[f"s{step}_perplexity"]) <= TOL * abs(g[f"s{step}_perplexity"])
+        assert abs(q.double().sum().item() - g[f"s{step}_quantized_sum"]) <= TOL * q.abs().double().sum().item()
+        assert rel_err(m.ema_cluster_size.cpu().numpy(), g[f"s{step}_state_ema_cluster_size"]) <= TOL
+        assert rel_err(m.ema_w.cpu().numpy(), g[f"s{step}_state_ema_w"]) <= TOL
+        assert rel_err(m.embedding.weight.detach().cpu().numpy(), g[f"s{step}_state_embedding_weight"]) <= TOL
+        assert np.array_equal(m.usage_count.cpu().numpy(), g[f"s{step}_state_usage_count"])
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_backward_matches_reference(mode, dev):
+    g = np.load(os.path.join(GOLDEN, f"g4_backward_{mode}.npz"))
+    K, D = g["E"].shape
+    m = make(K, D, float(g["beta"]), 0.95, g["E"], dev)
+    m.train(mode == "train")
+    z = torch.from_numpy(g["z"]).to(dev).requires_grad_(True)
+    q, loss, _ = m(z)
+    obj = float(g["a"]) * (q * torch.from_numpy(g["w"]).to(dev)).sum() + float(g["b"]) * loss
+    obj.backward()
+    assert abs(loss.item() - g["loss"]) <= TOL * abs(g["loss"])
+    assert rel_err(z.grad.cpu().numpy(), g["grad"]) <= TOL
+    assert m.embedding.weight.grad is None          # nothing flows to the codebook (reference :92, :95)
+
+
+def test_eval_under_no_grad_and_outer_no_grad_training(dev):
+    """The EMA branch keys on module.training, not on grad mode (reference :61): a training-mode
+    forward inside torch.no_grad() still updates the codebook."""
+    K, D = 128, 32
+    E = gauss(1, (K, D)) * np.float32(0.5)
+    m = make(K, D, 3.0, 0.95, E, dev)
+    z = torch.from_numpy(gauss(2, (4, D, 8, 8))).to(dev)
+    m.train()
+    with torch.no_grad():
+        m(z)
+    assert float(m.usage_count.sum()) == 4 * 64
+    before = m.embedding.weight.detach().clone()
+    m.eval()
+    m(z)
+    assert torch.equal(before, m.embedding.weight.detach())
+
+
+def test_state_dict_round_trip_and_strict_load(dev):
+    K, D = 256, 64
+    m = make(K, D, 3.0, 0.95, gauss(3, (K, D)), dev)
+    m.train()
+    z = torch.from_numpy(gauss(4, (4, D, 8, 8))).to(dev)
+    m(z)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    from vq_vae_amd import EMAVectorQuantizer
+    m2 = EMAVectorQuantizer(K, D, 3.0).to(dev)
+    m2.load_state_dict(sd, strict=True)
+    m2.train()
+    o1 = m(z)
+    o2 = m2(z)
+    assert torch.equal(o1[2][1], o2[2][1]) and torch.equal(o1[0], o2[0])
+    assert torch.equal(m.embedding.weight, m2.embedding.weight)
+
+
+def test_lazy_onehot_above_threshold(dev):
+    from vq_vae_amd import EMAVectorQuantizer, LazyOneHot
+    K, D = 512, 64
+    m = make(K, D, 3.0, 0.95, gauss(5, (K, D)), dev)
+    m.onehot_eager_bytes = 1024           # force the lazy form
+    m.eval()
+    z = torch.from_numpy(gauss(6, (2, D, 8, 8))).to(dev)
+    q, loss, (perp, idx, enc) = m(z)
+    assert isinstance(enc, LazyOneHot) and enc.shape == (128, K) and enc._dense is None
+    flat = enc.detach().flatten()          # what vqgan_trainer.py:143 does with "indices"
+    assert flat.shape == (128 * K,) and float(flat.sum()) == 128
+    assert torch.equal(torch.argmax(enc, dim=1), idx.view(-1))     # torch function protocol
+    assert enc.flatten().cpu().numpy().shape == (128 * K,)         # codebook_utilization_check.py:79
+
+
+def test_half_and_noncontiguous_inputs(dev):
+    K, D = 128, 32
+    E = gauss(7, (K, D)) * np.float32(0.5)
+    m = make(K, D, 3.0, 0.95, E, dev)
+    m.eval()
+    z = torch.from_numpy(gauss(8, (2, D, 8, 8))).to(dev)
+    ref = m(z)
+    nhwc = z.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)      # channels-last strides
+    assert not nhwc.is_contiguous()
+    out = m(nhwc)
+    assert torch.equal(out[2][1], ref[2][1]) and torch.equal(out[0], ref[0])
+    with torch.autocast("cuda", dtype=torch.float16):                   # validation runs under autocast
+        out16 = m(z)
+    assert torch.equal(out16[2][1], ref[2][1])                          # the search stays fp32
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(2, D + 1, 4, 4, device=dev))
+
+
+def test_maintenance_methods(dev):
+    K, D = 256, 32
+    m = make(K, D, 3.0, 0.95, gauss(9, (K, D)), dev)
+    m.train()
+    for s in range(3):
+        m(torch.from_numpy(gauss(20 + s, (2, D, 8, 8))).to(dev))
+    torch.manual_seed(0)
+    cs = m.ema_cluster_size.clone()
+    n_dead = m.reset_dead_codes(threshold=2, current_epoch=5)
+    assert n_dead == int((cs < 2).sum())
+    assert float(m.last_reset_epoch) == 5 and m.reset_dead_codes(threshold=2, current_epoch=6) == 0
+    dead = (cs < 2).nonzero().view(-1)
+    assert float(m.usage_count[dead].abs().sum()) == 0
+    n_low = m.reset_low_usage_codes(percentage=0.1, current_epoch=5)
+    assert n_low == max(1, int(K * 0.1)) and float(m.last_low_usage_reset_epoch) == 5
+    assert m.expand_codebook(K + 64) and m.embedding.weight.shape == (K + 64, D)
+    assert m.embedding.weight.is_cuda and m.ema_w.shape == (K + 64, D)
+    q, loss, (perp, idx, enc) = m(torch.from_numpy(gauss(30, (2, D, 8, 8))).to(dev))   # still runs after expansion
+    assert enc.shape[1] == K + 64 and int(idx.max()) < K + 64

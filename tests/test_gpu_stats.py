@@ -1,0 +1,178 @@
+"""GPU tests of the statistics kernels, the packed-key kernels and the row-sharded step."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from inputs import gauss
+from oracle import vq_oracle as vo
+from test_distributed_cpu import pack_key
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def numpy_index_stats(a, K):
+    """The literal NumPy expressions of vqvae/codebook_utilization_check.py:86-108."""
+    uniq = np.unique(a)
+    counts = np.bincount(a, minlength=K).astype(np.float64)
+    probs = counts / len(a)
+    valid = probs[probs > 0]
+    entropy = -np.sum(valid * np.log2(valid + 1e-10))
+    gini = 1 - np.sum((valid / np.mean(valid)) ** 2) / len(valid)
+    return {"utilization": len(uniq) / K, "entropy": entropy, "normalized_entropy": entropy / np.log2(K),
+            "gini": gini, "index_counts": counts, "probs": probs, "unique_indices": uniq}
+
+
+def torch_batch_stats(a, K):
+    """The torch fp32 expressions of vqvae/vqgan_trainer.py:594-612 on CPU."""
+    t = torch.from_numpy(a)
+    counts = torch.bincount(t, minlength=K).float()
+    probs = counts / counts.sum()
+    valid = probs[probs > 0]
+    ent = -torch.sum(valid * torch.log2(valid + 1e-10)).item()
+    return {"unique": len(torch.unique(t)), "entropy": ent,
+            "normalized_entropy": ent / torch.log2(torch.tensor(float(K))).item()}
+
+
+def index_sets(K, M, rng):
+    zipf = np.minimum(rng.zipf(1.1, M) - 1, K - 1).astype(np.int64)
+    return {"uniform": rng.integers(0, K, M, dtype=np.int64), "zipf": zipf,
+            "single": np.full(M, K // 3, np.int64), "all_codes": np.arange(M, dtype=np.int64) % K}
+
+
+@pytest.mark.parametrize("K,M", [(512, 20000), (8192, 1_000_000), (65536, 300_000)])
+def test_index_statistics(K, M, dev):
+    from vq_vae_amd import stats
+    rng = np.random.Generator(np.random.PCG64(7))
+    for name, a in index_sets(K, M, rng).items():
+        ref = numpy_index_stats(a, K)
+        got = stats.analyze_indices(torch.from_numpy(a).to(dev), K)
+        assert np.array_equal(got["index_counts"], ref["index_counts"]), name       # integers: exact
+        assert np.array_equal(got["unique_indices"], ref["unique_indices"])
+        assert got["utilization"] == ref["utilization"]
+        for key in ("entropy", "normalized_entropy", "gini"):
+            assert abs(got[key] - ref[key]) <= 1e-11 * max(1.0, abs(ref[key])), (name, key)
+        o = vo.index_stats_f64(ref["index_counts"].astype(np.int64), M)
+        assert abs(o["entropy"] - ref["entropy"]) <= 1e-11 * max(1.0, abs(ref["entropy"]))
+        assert abs(o["gini"] - ref["gini"]) <= 1e-11 * max(1.0, abs(ref["gini"]))
+        b = stats.batch_code_stats(torch.from_numpy(a).to(dev), K)
+        tb = torch_batch_stats(a, K)
+        assert b["unique"] == tb["unique"]
+        assert abs(b["entropy"] - tb["entropy"]) <= 2e-5 * max(1.0, abs(tb["entropy"]))
+        assert abs(b["normalized_entropy"] - tb["normalized_entropy"]) <= 2e-5
+
+
+def test_accumulating_over_batches(dev):
+    from vq_vae_amd import stats
+    K = 8192
+    rng = np.random.Generator(np.random.PCG64(8))
+    parts = [rng.integers(0, K, n, dtype=np.int64) for n in (100_000, 1, 33_333)]
+    acc = stats.CodeUsage(K, dev)
+    for p in parts:
+        acc.update(torch.from_numpy(p).to(dev))
+    ref = numpy_index_stats(np.concatenate(parts), K)
+    got = acc.result()
+    assert np.array_equal(got["index_counts"], ref["index_counts"])
+    assert abs(got["entropy"] - ref["entropy"]) <= 1e-11 * ref["entropy"]
+
+
+def test_count_used_codes(dev):
+    from vq_vae_amd import stats
+    K, D = 512, 64
+    E = gauss(1, (K, D)) * np.float32(0.5)
+    z = gauss(2, (8, D, 16, 16))
+    idx, _ = vo.search(z, E)
+    n = stats.count_used_codes(torch.from_numpy(z).to(dev), torch.from_numpy(E).to(dev))
+    assert n == len(np.unique(idx))
+    flat = np.transpose(z, (0, 2, 3, 1)).reshape(-1, D)                # vqtrainer.py:60 feeds (N, D)
+    assert stats.count_used_codes(torch.from_numpy(flat.copy()).to(dev), torch.from_numpy(E).to(dev)) == n
+
+
+@pytest.mark.parametrize("K,D", [(512, 64), (1000, 32), (8192, 256)])
+def test_pairwise_codebook_stats(K, D, dev):
+    from vq_vae_amd import stats
+    E = gauss(3, (K, D)) * np.float32(0.6)
+    E[K // 2] = E[5]                                   # a duplicated code: nearest-other distance 0
+    nn_d, nn_i, ref = vo.pairwise(E)
+    got = stats.pairwise_codebook_stats(torch.from_numpy(E).to(dev))
+    assert np.array_equal(got["nn_idx"].cpu().numpy(), nn_i)
+    assert np.array_equal(got["nn_dist"].cpu().numpy().view(np.uint32), nn_d.view(np.uint32))
+    assert got["min"] == ref["min"] and got["max"] == ref["max"]
+    assert abs(got["mean"] - ref["mean"]) <= 1e-9 * abs(ref["mean"])
+    # independent float64 check of the definition ||e_i - e_j||^2
+    if K <= 1000:
+        e64 = E.astype(np.float64)
+        P = ((e64[:, None, :] - e64[None, :, :]) ** 2).sum(-1)
+        np.fill_diagonal(P, np.inf)
+        assert rel_err(got["nn_dist"].cpu().numpy(), P.min(1)) <= 1e-5
+        off = P[np.isfinite(P)]
+        assert abs(got["mean"] - off.mean()) <= 1e-5 * off.mean()
+
+
+def test_pack_unpack_keys(dev):
+    from vq_vae_amd import ops
+    d = np.array([np.nan, -np.inf, -3.0, -0.0, 0.0, 1e-30, 2.5, np.inf, 7.25], np.float32)
+    idx = np.array([5, 4, 3, 2, 1, 0, 8, 7, 6], np.int64)
+    packed = ops.pack_dist_index(torch.from_numpy(d).to(dev), torch.from_numpy(idx).to(dev))
+    assert np.array_equal(packed.cpu().numpy(), pack_key(d, idx))
+    ws = ops.Workspace(dev)
+    d2, i64, i32 = ops.unpack_dist_index(packed, ws)
+    assert np.array_equal(i64.cpu().numpy(), idx) and np.array_equal(i32[:9].cpu().numpy(), idx.astype(np.int32))
+    back = d2.cpu().numpy()
+    assert np.isnan(back[0]) and np.array_equal(back[1:], np.where(d[1:] == 0, 0.0, d[1:]).astype(np.float32))
+
+
+def test_row_sharded_step_equals_unsharded(dev):
+    """K = 2048 sharded into 8 x 256 rows on one GPU: the merge is an elementwise int64 min over the
+    shards' packed keys (what the MIN all-reduce computes); indices, outputs and the updated
+    shards must equal the unsharded step."""
+    from vq_vae_amd import ops
+    from vq_vae_amd.distributed import shard_rows, sharded_quantize_step
+    K, D, P = 2048, 64, 8
+    E0 = gauss(4, (K, D)) * np.float32(0.7)
+    E0[1500] = E0[100]                                     # duplicate across shards
+    z = gauss(5, (8, D, 16, 16))
+    zt = torch.from_numpy(z).to(dev)
+    # unsharded
+    ws = ops.Workspace(dev)
+    full = {"E": torch.from_numpy(E0).to(dev), "ema_w": torch.zeros(K, D, device=dev),
+            "cs": torch.zeros(K, device=dev), "usage": torch.zeros(K, device=dev)}
+    ref = ops.quantize_step(zt, full["E"], full["ema_w"], full["cs"], full["usage"], beta=3.0, decay=0.95,
+                            epsilon=1e-5, temperature=1.0, training=True, ws=ws)
+    # sharded: phase 1 (search + pack) on every shard, then the merge, then phase 2 per shard
+    shards = []
+    for r in range(P):
+        lo, hi = shard_rows(K, r, P)
+        shards.append({"lo": lo, "E": torch.from_numpy(E0[lo:hi].copy()).to(dev),
+                       "ema_w": torch.zeros(hi - lo, D, device=dev), "cs": torch.zeros(hi - lo, device=dev),
+                       "usage": torch.zeros(hi - lo, device=dev), "ws": ops.Workspace(dev)})
+    packs = []
+    for s in shards:
+        r_ = ops.search(zt, s["E"], s["ws"], code_base=s["lo"], want_quantized=False, want_dmin=True)
+        packs.append(ops.pack_dist_index(r_["dmin"], r_["indices"]))
+    merged = torch.stack(packs).min(0).values
+    E_full = torch.cat([s["E"] for s in shards], 0).clone()
+    # Laplace normaliser: sum over shards of the local EMA'd cluster sizes (first step: cs = 0.05 * counts)
+    counts = vo.histogram(ref.indices.cpu().numpy(), K)
+    n_total = torch.tensor(float(np.float32(1 - 0.95)) * counts.astype(np.float64).sum(), dtype=torch.float64, device=dev)
+    outs = []
+    for s in shards:
+        outs.append(sharded_quantize_step(zt, s["E"], s["ema_w"], s["cs"], s["usage"], K_total=K, code_base=s["lo"],
+                                          beta=3.0, decay=0.95, epsilon=1e-5, temperature=1.0, training=True,
+                                          ws=s["ws"], merge=lambda p: merged.clone(),
+                                          gather_codebook=lambda e: E_full, sum_scalar=lambda n: n_total))
+    for o in outs:
+        assert torch.equal(o.indices, ref.indices)
+        assert torch.equal(o.quantized, ref.quantized)
+        assert abs(o.loss.item() - ref.loss.item()) <= 1e-6 * abs(ref.loss.item())
+        assert abs(o.perplexity.item() - ref.perplexity.item()) <= 1e-6 * ref.perplexity.item()
+    assert rel_err(torch.cat([s["E"] for s in shards]).cpu().numpy(), full["E"].cpu().numpy()) <= 1e-5
+    assert rel_err(torch.cat([s["cs"] for s in shards]).cpu().numpy(), full["cs"].cpu().numpy()) <= 1e-5
+    assert torch.equal(torch.cat([s["usage"] for s in shards]), full["usage"])
+    assert torch.equal(torch.cat([s["ema_w"] for s in shards]), full["ema_w"])

@@ -148,7 +148,8 @@ __global__ __launch_bounds__(1024) void vq_pairwise_finish_kernel(const double* 
 
 __device__ __forceinline__ uint32_t ordered_key(float d) {
   if (d != d) return 0u;  // NaN sorts first, as torch.argmin treats it
-  const uint32_t u = __float_as_uint(d);
+  uint32_t u = __float_as_uint(d);
+  if ((u << 1) == 0u) u = 0u;  // -0.0 and +0.0 compare equal in torch.argmin: one key for both
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 

@@ -63,3 +63,62 @@ def merge_packed_winners(packed_i64: torch.Tensor, group: Optional[dist.ProcessG
     then lowest index), so an elementwise MIN over ranks picks the global winner."""
     dist.all_reduce(packed_i64, op=dist.ReduceOp.MIN, group=group)
     return packed_i64
+
+
+def sharded_quantize_step(z: torch.Tensor, E_shard: torch.Tensor, ema_w_shard, cluster_size_shard, usage_shard, *,
+                          K_total: int, code_base: int, beta: float, decay: float, epsilon: float,
+                          temperature: float, training: bool, ws, group: Optional[dist.ProcessGroup] = None,
+                          merge=None, gather_codebook=None, sum_scalar=None):
+    """Forward of a quantizer whose codebook rows are sharded over the ranks of ``group``
+    (large codebooks, e.g. K = 65536 as 8 x 8192 rows); every rank sees the same rows ``z``.
+
+    Exchange steps: (1) an int64 MIN all-reduce of the packed (distance, index) winners, N*8
+    bytes; (2) an all-gather of the codebook shards for the gather of the quantized output,
+    K*D*4 bytes; (3) one scalar SUM for the Laplace normaliser n = sum(cluster_size).  Each rank
+    then updates only its own rows.  ``merge`` / ``gather_codebook`` / ``sum_scalar`` default to
+    the torch.distributed collectives and can be replaced (single-process tests).
+    """
+    from . import ops
+    from ._lib import check, load
+    lib = load()
+    K_loc, D = E_shard.shape
+    r = ops.search(z, E_shard, ws, temperature=temperature, code_base=code_base, want_quantized=False,
+                   want_dmin=True)
+    packed = ops.pack_dist_index(r["dmin"], r["indices"])
+    packed = merge(packed) if merge is not None else merge_packed_winners(packed, group)
+    _, idx64, idx32 = ops.unpack_dist_index(packed, ws, want_dmin=False)
+    N = r["N"]
+    # quantized output: needs the winners' rows, wherever they live
+    if gather_codebook is not None:
+        E_full = gather_codebook(E_shard)
+    else:
+        world = dist.get_world_size(group)
+        parts = [torch.empty_like(E_shard) for _ in range(world)]
+        dist.all_gather(parts, E_shard.contiguous(), group=group)
+        E_full = torch.cat(parts, 0)[:K_total].contiguous()
+    q, lp, n_partial = ops.gather_st(z, E_full, idx64, ws)
+    counts_full = ops.histogram(idx32[:N], K_total, ws)          # every rank has all winners
+    loss, perp, _ = ops.step_scalars(lp, n_partial, N, D, beta, counts_full, K_total, z.device)
+    if training:
+        slabs, _ = ops.embed_sums(ops._f32c(z, "latents"), idx32, K_loc, ws, code_base=code_base, zmax_valid=True)
+        counts_loc = counts_full[code_base: code_base + K_loc].contiguous()
+        d, omd, eps, _ = ops.ema_scalars(K_total, decay, epsilon)
+        keps = ops.ema_scalars(K_total, decay, epsilon)[3]
+        # cluster sizes: local EMA, global Laplace normaliser
+        c = (counts_loc.to(torch.int64) & 0xFFFFFFFF).float()
+        usage_shard += c
+        cluster_size_shard.mul_(d).add_(c * omd)
+        n = cluster_size_shard.double().sum()
+        n = sum_scalar(n) if sum_scalar is not None else _all_reduce_sum(n, group)
+        n = n.float()
+        cluster_size_shard.copy_((cluster_size_shard + eps) / (n + keps) * n)
+        check(lib.vq_ema_codebook_update(ops._ptr(slabs), slabs.shape[0], K_loc, D, d, omd,
+                                         ops._ptr(cluster_size_shard), ops._ptr(ema_w_shard), ops._ptr(E_shard),
+                                         ops._stream(z.device)), "vq_ema_codebook_update")
+    return ops.StepResult(q, loss, perp, idx64, counts_full, None)
+
+
+def _all_reduce_sum(t: torch.Tensor, group) -> torch.Tensor:
+    t = t.clone()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t

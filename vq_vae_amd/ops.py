@@ -274,3 +274,26 @@ def quantize_step(z: torch.Tensor, E: torch.Tensor, ema_w, cluster_size, usage, 
         if training:
             ema_update(None, dw, usage, cluster_size, ema_w, E, decay, epsilon, counts64=counts64)
     return StepResult(r["quantized"], loss, perp, r["indices"], counts, r["dmin"])
+
+
+def pack_dist_index(dmin: torch.Tensor, idx64: torch.Tensor) -> torch.Tensor:
+    """int64 keys whose signed order is torch.argmin's order over (distance, index)."""
+    lib = _lib.load()
+    N = idx64.numel()
+    packed = torch.empty(N, dtype=torch.int64, device=idx64.device)
+    check(lib.vq_pack_dist_index(_ptr(dmin), _ptr(idx64), N, _ptr(packed), _stream(idx64.device)),
+          "vq_pack_dist_index")
+    return packed
+
+
+def unpack_dist_index(packed: torch.Tensor, ws: Workspace, want_dmin: bool = True):
+    """Returns (dmin|None, idx64, idx32) of the winners in ``packed``."""
+    lib = _lib.load()
+    N = packed.numel()
+    dev = packed.device
+    dmin = torch.empty(N, dtype=torch.float32, device=dev) if want_dmin else None
+    idx64 = torch.empty(N, dtype=torch.int64, device=dev)
+    idx32 = ws.get("idx32", N * 4, torch.int32)
+    check(lib.vq_unpack_dist_index(_ptr(packed), N, _ptr(dmin), _ptr(idx64), _ptr(idx32), _stream(dev)),
+          "vq_unpack_dist_index")
+    return dmin, idx64, idx32
