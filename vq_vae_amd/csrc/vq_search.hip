@@ -58,14 +58,20 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // Issue the LDS-DMA copy of one codebook stage.  The image is lane-linear, so piece p of
 // the stage (1 KiB) goes to LDS offset p*1024; lane l supplies bytes [16l, 16l+16).
-template <int D>
+template <int D, int NW>
 __device__ __forceinline__ void stage_copy(const float* image, int stage, float* lds_buf, int wave, int lane) {
+  // With 8 waves only waves 0-3 issue the DMA.  Waves w and w+4 share a SIMD: while the first
+  // one spends ~1.5k cycles issuing its 16-17 pieces, its partner already runs MFMAs, and for
+  // the rest of the stage the two stay out of phase -- one wave's scan of a finished tile then
+  // falls into the other's pure MFMA stretch instead of colliding with the partner's own scan.
+  constexpr int NL = NW == 8 ? 4 : NW;  // loader waves
   constexpr int PIECES = D / 4 + 1;
+  if (wave >= NL) return;
   const char* src = reinterpret_cast<const char*>(image) + (size_t)stage * vq_stage_floats(D) * 4 + lane * 16;
   char* dst = reinterpret_cast<char*>(lds_buf);
 #pragma unroll
-  for (int i = 0; i < (PIECES + 3) / 4; ++i) {
-    const int p = i * 4 + wave;
+  for (int i = 0; i < (PIECES + NL - 1) / NL; ++i) {
+    const int p = i * NL + wave;
     if (p < PIECES) {
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(src + (size_t)p * 1024),
@@ -105,8 +111,12 @@ __device__ __forceinline__ void scan_tile(const f32x16& c, const f32x4 (&e2v)[4]
   }
 }
 
-template <int D, bool NCHW, bool TEMP, bool PAIRWISE>
-__global__ __launch_bounds__(256, 1) void vq_search_mfma_kernel(SearchArgs a) {
+// CT = 32-latent column tiles per wave.  CT = 2: 4 waves, one per SIMD, 512 registers each.
+// CT = 1: 8 waves, two per SIMD, 256 registers each -- the partner wave's MFMAs cover a wave's
+// scan, DMA issue and LDS waits.
+template <int D, int CT, bool NCHW, bool TEMP, bool PAIRWISE>
+__global__ __launch_bounds__(512 / CT, 2 / CT) void vq_search_mfma_kernel(SearchArgs a) {
+  constexpr int NW = 8 / CT;  // waves per workgroup
   constexpr int S = D / 2;  // k-steps of the 32x32x2 MFMA
   constexpr int G = D / 8;  // ds_read_b128 groups (4 k-steps each)
   constexpr int STAGE_F = VQ_STAGE_CODES * D + 256;
@@ -115,14 +125,14 @@ __global__ __launch_bounds__(256, 1) void vq_search_mfma_kernel(SearchArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 31, h = lane >> 5;
-  const int64_t row0 = (int64_t)blockIdx.x * VQ_WG_ROWS + wave * 64;
+  const int64_t row0 = (int64_t)blockIdx.x * VQ_WG_ROWS + wave * (32 * CT);
 
   // A non-finite codebook sends every row to the exact kernel.
   if (a.control[VQ_CTL_CB_FLAG] != 0) {
     if (threadIdx.x == 0 && a.loss_partial) a.loss_partial[blockIdx.x] = 0.0f;
     if (h == 0) {
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
+      for (int ct = 0; ct < CT; ++ct) {
         const int64_t n = row0 + ct * 32 + j;
         if (n < a.N) a.nf_rows[atomicAdd(&a.control[VQ_CTL_NF_COUNT], 1)] = (int32_t)n;
       }
@@ -131,16 +141,16 @@ __global__ __launch_bounds__(256, 1) void vq_search_mfma_kernel(SearchArgs a) {
   }
 
   // Prologue DMA of stage 0 goes out first; it lands while z is being loaded.
-  stage_copy<D>(a.image, 0, lds, wave, lane);
+  stage_copy<D, NW>(a.image, 0, lds, wave, lane);
 
   // ---- z tile into registers, in B-operand order: zr[ct][s] = z[row][2s + h] -----------
-  float zr[2][S];
-  float z2[2];
-  int64_t zoff[2];            // element offset of this lane's first channel of the row
+  float zr[CT][S];
+  float z2[CT];
+  int64_t zoff[CT];            // element offset of this lane's first channel of the row
   int64_t zstride = 2 * a.HW;  // NCHW: elements between channels 2s+h and 2s+2+h
   uint32_t zmax_bits = 0;      // max |z| of this lane's values (bit pattern), for the EMA scatter's scaling
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
+  for (int ct = 0; ct < CT; ++ct) {
     int64_t n = row0 + ct * 32 + j;
     if (n >= a.N) n = a.N - 1;  // clamped duplicate: loads stay in bounds, outputs are masked
     float p = 0.0f;
@@ -183,25 +193,31 @@ __global__ __launch_bounds__(256, 1) void vq_search_mfma_kernel(SearchArgs a) {
     if (lane == 0 && zmax_bits) atomicMax(reinterpret_cast<unsigned int*>(&a.control[VQ_CTL_ZMAX]), zmax_bits);
   }
 
-  float best[2] = {__builtin_inff(), __builtin_inff()};
-  int bidx[2] = {0, 0};
-  double psum[2] = {0.0, 0.0};
-  float pmin[2] = {__builtin_inff(), __builtin_inff()};
-  float pmax[2] = {-__builtin_inff(), -__builtin_inff()};
-  int self_code[2] = {-1, -1};
-  if (PAIRWISE) {
-    // the row index is the code index; remove the 4*h part the scan leaves out
-    self_code[0] = (int)(row0 + j) - 4 * h;
-    self_code[1] = (int)(row0 + 32 + j) - 4 * h;
+  float best[CT];
+  int bidx[CT];
+  double psum[CT];
+  float pmin[CT], pmax[CT];
+  int self_code[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    best[ct] = __builtin_inff();
+    bidx[ct] = 0;
+    psum[ct] = 0.0;
+    pmin[ct] = __builtin_inff();
+    pmax[ct] = -__builtin_inff();
+    // pairwise: the row index is the code index; remove the 4*h part the scan leaves out
+    self_code[ct] = PAIRWISE ? (int)(row0 + 32 * ct + j) - 4 * h : -1;
   }
 
   // Accumulator set B (second 32 codes of a stage) is scanned one stage late, under the
   // MFMAs of the next stage's first half.  Before the first stage it holds zeros and its
   // norms are +inf, so that first scan changes nothing.
-  f32x16 cB0, cB1;
+  f32x16 cA[CT], cB[CT];
   f32x4 e2B[4];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { cB0[i] = 0.0f; cB1[i] = 0.0f; }
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) cB[ct][i] = 0.0f;
 #pragma unroll
   for (int q = 0; q < 4; ++q) e2B[q] = f32x4{__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()};
 
@@ -210,47 +226,52 @@ __global__ __launch_bounds__(256, 1) void vq_search_mfma_kernel(SearchArgs a) {
   int cur = 0;
   for (int st = 0; st < a.nstages; ++st) {
     float* buf = lds + cur * STAGE_F;
-    if (st + 1 < a.nstages) stage_copy<D>(a.image, st + 1, lds + (cur ^ 1) * STAGE_F, wave, lane);
+    if (st + 1 < a.nstages) stage_copy<D, NW>(a.image, st + 1, lds + (cur ^ 1) * STAGE_F, wave, lane);
 
     const f32x4* A = reinterpret_cast<const f32x4*>(buf) + lane;
     const f32x4* e2s = reinterpret_cast<const f32x4*>(buf + VQ_STAGE_CODES * D) + h;
 
     // ---- first half: codes [64 st, 64 st + 32) into set A; scan set B of stage st-1 -----
-    f32x16 cA0, cA1;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { cA0[i] = 0.0f; cA1[i] = 0.0f; }
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) cA[ct][i] = 0.0f;
     {
       f32x4 af = A[0];
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const f32x4 an = A[(g + 1 < G ? g + 1 : g) * 64];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          cA0 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], zr[0][4 * g + q], cA0, 0, 0, 0);
-          cA1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], zr[1][4 * g + q], cA1, 0, 0, 0);
-        }
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct)
+            cA[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], zr[ct][4 * g + q], cA[ct], 0, 0, 0);
         af = an;
       }
     }
     {
       const int code0 = (st - 1) * VQ_STAGE_CODES + 32;
-      scan_tile<TEMP, PAIRWISE>(cB0, e2B, z2[0], code0, a.T, self_code[0], best[0], bidx[0], psum[0], pmin[0], pmax[0]);
-      scan_tile<TEMP, PAIRWISE>(cB1, e2B, z2[1], code0, a.T, self_code[1], best[1], bidx[1], psum[1], pmin[1], pmax[1]);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+        scan_tile<TEMP, PAIRWISE>(cB[ct], e2B, z2[ct], code0, a.T, self_code[ct], best[ct], bidx[ct], psum[ct],
+                                  pmin[ct], pmax[ct]);
     }
 
     // ---- second half: codes [64 st + 32, 64 st + 64) into set B; scan set A --------------
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { cB0[i] = 0.0f; cB1[i] = 0.0f; }
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) cB[ct][i] = 0.0f;
     {
       f32x4 af = A[G * 64];
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const f32x4 an = A[(G + (g + 1 < G ? g + 1 : g)) * 64];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          cB0 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], zr[0][4 * g + q], cB0, 0, 0, 0);
-          cB1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], zr[1][4 * g + q], cB1, 0, 0, 0);
-        }
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct)
+            cB[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], zr[ct][4 * g + q], cB[ct], 0, 0, 0);
         af = an;
       }
     }
@@ -259,8 +280,10 @@ __global__ __launch_bounds__(256, 1) void vq_search_mfma_kernel(SearchArgs a) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) e2A[q] = e2s[2 * q];
       const int code0 = st * VQ_STAGE_CODES;
-      scan_tile<TEMP, PAIRWISE>(cA0, e2A, z2[0], code0, a.T, self_code[0], best[0], bidx[0], psum[0], pmin[0], pmax[0]);
-      scan_tile<TEMP, PAIRWISE>(cA1, e2A, z2[1], code0, a.T, self_code[1], best[1], bidx[1], psum[1], pmin[1], pmax[1]);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+        scan_tile<TEMP, PAIRWISE>(cA[ct], e2A, z2[ct], code0, a.T, self_code[ct], best[ct], bidx[ct], psum[ct],
+                                  pmin[ct], pmax[ct]);
     }
     // norms of this stage's second half, kept for the deferred scan
 #pragma unroll
@@ -271,14 +294,16 @@ __global__ __launch_bounds__(256, 1) void vq_search_mfma_kernel(SearchArgs a) {
   }
   {
     const int code0 = (a.nstages - 1) * VQ_STAGE_CODES + 32;
-    scan_tile<TEMP, PAIRWISE>(cB0, e2B, z2[0], code0, a.T, self_code[0], best[0], bidx[0], psum[0], pmin[0], pmax[0]);
-    scan_tile<TEMP, PAIRWISE>(cB1, e2B, z2[1], code0, a.T, self_code[1], best[1], bidx[1], psum[1], pmin[1], pmax[1]);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+      scan_tile<TEMP, PAIRWISE>(cB[ct], e2B, z2[ct], code0, a.T, self_code[ct], best[ct], bidx[ct], psum[ct],
+                                pmin[ct], pmax[ct]);
   }
 
   // ---- merge the two lane halves (rows +0..3 vs +4..7 of every 8), write the winners ----
   float lp = 0.0f;
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
+  for (int ct = 0; ct < CT; ++ct) {
     int bi = bidx[ct] + 4 * h;
     float b = best[ct];
     const float ob = __shfl_xor(b, 32);
@@ -338,17 +363,27 @@ __global__ __launch_bounds__(256, 1) void vq_search_mfma_kernel(SearchArgs a) {
   }
 
   // ---- per-workgroup partials (fixed reduction order: reproducible) ---------------------
-  float* red = lds + 2 * STAGE_F;  // 16 floats past the stage buffers
+  float* red = lds + 2 * STAGE_F;  // 64 floats past the stage buffers
   if (a.q_out != nullptr && a.loss_partial != nullptr) {
     const float ws = wave_sum(lp);
     if (lane == 0) red[wave] = ws;
     __syncthreads();
-    if (threadIdx.x == 0) a.loss_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) {
+      float tot;
+      if (NW == 4) tot = (red[0] + red[1]) + (red[2] + red[3]);
+      else tot = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+      a.loss_partial[blockIdx.x] = tot;
+    }
   }
   if (PAIRWISE) {
-    double sd = psum[0] + psum[1];
-    float mn = pmin[0] < pmin[1] ? pmin[0] : pmin[1];
-    float mx = pmax[0] > pmax[1] ? pmax[0] : pmax[1];
+    double sd = 0.0;
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      sd += psum[ct];
+      mn = pmin[ct] < mn ? pmin[ct] : mn;
+      mx = pmax[ct] > mx ? pmax[ct] : mx;
+    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
       sd += __shfl_xor(sd, off);
@@ -356,13 +391,20 @@ __global__ __launch_bounds__(256, 1) void vq_search_mfma_kernel(SearchArgs a) {
       mn = o1 < mn ? o1 : mn;
       mx = o2 > mx ? o2 : mx;
     }
-    double* redd = reinterpret_cast<double*>(red + 4);
-    if (lane == 0) { redd[wave] = sd; red[12 + wave] = mn; red[16 + wave] = mx; }
+    double* redd = reinterpret_cast<double*>(red + 8);   // 8 doubles
+    float* rmn = red + 24;                               // 8 floats
+    float* rmx = red + 32;                               // 8 floats
+    if (lane == 0) { redd[wave] = sd; rmn[wave] = mn; rmx[wave] = mx; }
     __syncthreads();
     if (threadIdx.x == 0) {
-      a.pw_sum[blockIdx.x] = (redd[0] + redd[1]) + (redd[2] + redd[3]);
-      float m0 = red[12], m1 = red[16];
-      for (int w = 1; w < 4; ++w) { m0 = red[12 + w] < m0 ? red[12 + w] : m0; m1 = red[16 + w] > m1 ? red[16 + w] : m1; }
+      double tot = 0.0;
+      float m0 = rmn[0], m1 = rmx[0];
+      for (int w = 0; w < NW; ++w) {
+        tot += redd[w];
+        m0 = rmn[w] < m0 ? rmn[w] : m0;
+        m1 = rmx[w] > m1 ? rmx[w] : m1;
+      }
+      a.pw_sum[blockIdx.x] = tot;
       a.pw_minmax[2 * blockIdx.x] = m0;
       a.pw_minmax[2 * blockIdx.x + 1] = m1;
     }
@@ -607,10 +649,10 @@ __global__ __launch_bounds__(256) void vq_gather_st_kernel(const float* __restri
   if (t == 0 && loss_partial) loss_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-template <int D, bool NCHW, bool TEMP, bool PAIRWISE>
+template <int D, int CT, bool NCHW, bool TEMP, bool PAIRWISE>
 int launch_mfma(const SearchArgs& a, hipStream_t s) {
-  const size_t lds_bytes = 2 * vq_stage_floats(D) * 4 + 128;
-  auto kern = vq_search_mfma_kernel<D, NCHW, TEMP, PAIRWISE>;
+  const size_t lds_bytes = 2 * vq_stage_floats(D) * 4 + 256;
+  auto kern = vq_search_mfma_kernel<D, CT, NCHW, TEMP, PAIRWISE>;
   static bool attr_done[64] = {};  // per instantiation and device
   int dev = 0;
   VQ_CHECK_HIP(hipGetDevice(&dev));
@@ -620,15 +662,23 @@ int launch_mfma(const SearchArgs& a, hipStream_t s) {
     attr_done[dev & 63] = true;
   }
   const int64_t blocks = (a.N + VQ_WG_ROWS - 1) / VQ_WG_ROWS;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_bytes, s, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512 / CT), lds_bytes, s, a);
   return vq_hip_status(hipGetLastError());
 }
 
+// Column tiles per wave for each channel count (see the kernel's comment).
+#ifndef VQ_CT_256
+#define VQ_CT_256 1
+#endif
+template <int D> struct TileChoice { static constexpr int CT = 1; };
+template <> struct TileChoice<256> { static constexpr int CT = VQ_CT_256; };
+
 template <int D>
 int dispatch_mfma(const SearchArgs& a, bool nchw, bool temp, bool pairwise, hipStream_t s) {
-  if (pairwise) return launch_mfma<D, false, false, true>(a, s);
-  if (nchw) return temp ? launch_mfma<D, true, true, false>(a, s) : launch_mfma<D, true, false, false>(a, s);
-  return temp ? launch_mfma<D, false, true, false>(a, s) : launch_mfma<D, false, false, false>(a, s);
+  constexpr int CT = TileChoice<D>::CT;
+  if (pairwise) return launch_mfma<D, CT, false, false, true>(a, s);
+  if (nchw) return temp ? launch_mfma<D, CT, true, true, false>(a, s) : launch_mfma<D, CT, true, false, false>(a, s);
+  return temp ? launch_mfma<D, CT, false, true, false>(a, s) : launch_mfma<D, CT, false, false, false>(a, s);
 }
 
 int run_mfma(const SearchArgs& a, int D, bool nchw, bool temp, bool pairwise, hipStream_t s) {
