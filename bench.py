@@ -56,6 +56,24 @@ def cpu_baseline(rows: int = 16384, reps: int = 3) -> dict:
                       f"{rows} vectors/step, median of {reps} steps ({med:.3f} s/step), torch {torch.__version__} CPU"}
 
 
+def measured_traffic(rows: int):
+    """HBM bytes per launch of the search kernel from the committed rocprofv3 PMC passes
+    (profiles/r1_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction), when the
+    profile was taken on this workload; None otherwise.  bench.py cannot collect PMC counters itself."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
+            prof = json.load(f)
+        w = prof["workload"]
+        if (w["K"], w["D"], w["rows"]) != (K, D, rows):
+            return None
+        for k in prof["kernels"]:
+            if k["kernel"].startswith("vq_search_mfma_kernel"):
+                return float(k["hbm_bytes_corrected"])
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,7 +170,8 @@ def main() -> None:
                        "rows_per_gpu": rows, "parallelism": f"dp{world}" if world > 1 else "single"},
             "roofline": {"bound": "mfma", "kernel": "vq_search_mfma_kernel<256,NCHW>", "achieved": achieved,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                         "traffic": None, "ms_per_launch": search_ms,
+                         "traffic": measured_traffic(rows), "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
+                         "algorithmic_hbm_bytes": rows * (2 * D * 4 + 12), "ms_per_launch": search_ms,
                          "flops_per_launch": flops},
             "perplexity": float(out.perplexity.item()),
         }

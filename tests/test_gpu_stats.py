@@ -176,3 +176,38 @@ def test_row_sharded_step_equals_unsharded(dev):
     assert rel_err(torch.cat([s["cs"] for s in shards]).cpu().numpy(), full["cs"].cpu().numpy()) <= 1e-5
     assert torch.equal(torch.cat([s["usage"] for s in shards]), full["usage"])
     assert torch.equal(torch.cat([s["ema_w"] for s in shards]), full["ema_w"])
+
+
+def test_data_parallel_hook_over_rccl_single_rank(dev):
+    """The data-parallel path end to end on the GPU with a one-rank RCCL group: the all-reduces
+    run on device tensors and the step must reproduce the plain step bit for bit."""
+    import os
+    import torch.distributed as dist
+    from vq_vae_amd import ops
+    from vq_vae_amd.distributed import make_stats_reduce
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        created = True
+    try:
+        K, D = 512, 64
+        E0 = gauss(81, (K, D)) * np.float32(0.5)
+        z = torch.from_numpy(gauss(82, (8, D, 16, 16))).to(dev)
+        outs = []
+        for hook in (None, make_stats_reduce(), make_stats_reduce(uneven_rows=True)):
+            st = {"E": torch.from_numpy(E0).to(dev), "ema_w": torch.zeros(K, D, device=dev),
+                  "cs": torch.zeros(K, device=dev), "usage": torch.zeros(K, device=dev)}
+            o = ops.quantize_step(z, st["E"], st["ema_w"], st["cs"], st["usage"], beta=3.0, decay=0.95, epsilon=1e-5,
+                                  temperature=1.0, training=True, ws=ops.Workspace(dev), stats_reduce=hook)
+            outs.append((o, st))
+        ref, rst = outs[0]
+        for o, st in outs[1:]:
+            assert torch.equal(o.indices, ref.indices) and torch.equal(o.quantized, ref.quantized)
+            assert o.loss.item() == ref.loss.item() and o.perplexity.item() == ref.perplexity.item()
+            for k in rst:
+                assert torch.equal(st[k], rst[k]), k
+    finally:
+        if created:
+            dist.destroy_process_group()
