@@ -47,6 +47,7 @@ size_t vq_norms_bytes(int K);                   /* squared norms of the (padded)
 int64_t vq_search_blocks(int64_t N);            /* workgroups of vq_search = loss partials it writes*/
 size_t vq_loss_partial_bytes(int64_t N);        /* floats: vq_search_blocks(N) + fix-up partials   */
 size_t vq_control_bytes(void);                  /* small block of control words                    */
+size_t vq_search_split_bytes(int64_t N, int K); /* scratch of the small-batch codebook split (0: unused)*/
 int vq_scatter_slabs(int64_t N, int K, int D);  /* number of partial-sum slabs vq_ema_scatter writes*/
 
 /*
@@ -76,11 +77,16 @@ int vq_codebook_prep(const float* E, int K, int D, float* image, float* e2, int3
  *   loss_partial [vq_loss_partial_bytes/4] per-workgroup sums of (q - z)^2, may be NULL
  *   nf_rows      [N] int32 scratch: rows routed to the exact path (non-finite input)
  *   control      control words (nf counter, codebook flag)
+ *   split_ws     vq_search_split_bytes(N, K) bytes of scratch, may be NULL.  With fewer than
+ *                32 Ki rows the row tiles alone cannot fill 256 CUs; given this scratch (and
+ *                idx64) the codebook sweep is split over extra workgroups and merged, with
+ *                identical results.
  * Ties go to the lowest index; NaN handling follows torch.argmin.
  */
 int vq_search(const float* z, int layout, int64_t N, int D, int64_t HW, const float* E, const float* image,
               const float* e2, int K, float temperature, int64_t code_base, int64_t* idx64, int32_t* idx32,
-              float* dmin, float* q_out, float* loss_partial, int32_t* nf_rows, int32_t* control, void* stream);
+              float* dmin, float* q_out, float* loss_partial, int32_t* nf_rows, int32_t* control, void* split_ws,
+              void* stream);
 
 /* Same search through the exact scalar kernel only (any D <= 4096); used as the in-library
  * cross-check of the MFMA kernel and for shapes the MFMA kernel does not cover. */
@@ -91,7 +97,8 @@ int vq_search_exact(const float* z, int layout, int64_t N, int D, int64_t HW, co
 /*
  * Gather + straight-through + loss partials for given indices (used after a sharded
  * search has merged its winners).  ref: vqvae/ema_vector_quantizer.py:58, :92, :95, :98.
- * loss_partial gets vq_search_blocks(N) floats.
+ * loss_partial gets vq_search_blocks(N) floats.  Rows whose index is outside [0, K) are
+ * skipped: no output is written for them and they add nothing to the loss.
  */
 int vq_gather_st(const float* z, int layout, int64_t N, int D, int64_t HW, const float* E, int K,
                  const int64_t* idx64, float* q_out, float* loss_partial, void* stream);

@@ -45,6 +45,9 @@ def test_size_helpers():
     assert lib.vq_loss_partial_bytes(4096) == (16 + 1024) * 4
     assert lib.vq_scatter_slabs(4194304, 8192, 256) >= 4
     assert lib.vq_scatter_slabs(128, 512, 64) == 1
+    # codebook split scratch: only for small batches with enough stages
+    assert lib.vq_search_split_bytes(4194304, 8192) == 0 and lib.vq_search_split_bytes(8192, 64) == 0
+    assert lib.vq_search_split_bytes(8192, 8192) == 8 * 8192 * 8
     assert lib.vq_status_string(0) == b"ok"
     assert lib.vq_status_string(1) == b"invalid argument"
 
@@ -55,7 +58,7 @@ def test_entry_points_reject_bad_arguments_without_a_gpu():
     # argument validation happens before any HIP call
     assert lib.vq_codebook_prep(None, 512, 64, None, None, None, None) == 1
     assert lib.vq_search(None, 1, 128, 64, 64, None, None, None, 512, 1.0, 0, None, None, None, None, None, None,
-                         None, None) == 1
+                         None, None, None) == 1
     assert lib.vq_code_histogram(None, 0, 10, 512, None, 0, None, None) == 1
     assert lib.vq_ema_scatter(None, 1, 128, 64, 64, None, 512, 0, 0, None, None, None) == 1
 

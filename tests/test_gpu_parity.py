@@ -78,6 +78,34 @@ def test_search_bit_exact(K, D, shape, dev, ops):
     assert torch.equal(rx["quantized"].view(torch.int32), r["quantized"].view(torch.int32))
 
 
+@pytest.mark.parametrize("K,D,shape", [(8192, 256, (8, 256, 32, 32)), (8192, 256, (3000, 256)),
+                                       (1024, 64, (1, 64, 20, 20)), (8192, 256, (1, 256, 3, 3))])
+def test_small_batch_codebook_split(K, D, shape, dev, ops):
+    """Batches below 32 Ki rows split the codebook sweep over extra workgroups; results must be
+    identical to the unsplit sweep and to the oracle, non-finite rows included."""
+    z = gauss(91, shape)
+    E = gauss(92, (K, D)) * np.float32(0.8)
+    E[K - 3] = E[5]                                      # duplicate in the last split: lowest index wins
+    if len(shape) == 4:
+        z[0, :, 0, 0] = E[5]
+        z[0, 3, 1, 1] = np.nan
+    else:
+        z[0] = E[5]
+        z[7, 9] = np.inf
+    ws = ops.Workspace(dev)
+    zt, Et = _t(z, dev), _t(E, dev)
+    a = ops.search(zt, Et, ws, want_quantized=True, want_dmin=True, allow_split=True)
+    b = ops.search(zt, Et, ws, want_quantized=True, want_dmin=True, allow_split=False)
+    assert torch.equal(a["indices"], b["indices"]) and torch.equal(a["idx32"][: a["N"]], b["idx32"][: b["N"]])
+    assert torch.equal(a["dmin"].view(torch.int32), b["dmin"].view(torch.int32))
+    assert torch.equal(a["quantized"].view(torch.int32), b["quantized"].view(torch.int32))
+    sa = float(a["loss_partial"][: a["n_partial"]].double().sum()); sb = float(b["loss_partial"][: b["n_partial"]].double().sum())
+    assert (np.isnan(sa) and np.isnan(sb)) or abs(sa - sb) <= 1e-6 * abs(sb) or (np.isinf(sa) and sa == sb)
+    idx_o, dmin_o = vo.search(z, E)
+    assert np.array_equal(a["indices"].cpu().numpy(), idx_o)
+    assert int(idx_o[0]) == 5
+
+
 @pytest.mark.parametrize("T", [2.5, 0.7])
 def test_search_temperature(T, dev, ops):
     K, D = 512, 64

@@ -23,11 +23,13 @@ SIGNATURES = {
     "vq_search_blocks": (c_int64, [c_int64]),
     "vq_loss_partial_bytes": (c_size_t, [c_int64]),
     "vq_control_bytes": (c_size_t, []),
+    "vq_search_split_bytes": (c_size_t, [c_int64, c_int]),
     "vq_scatter_slabs": (c_int, [c_int64, c_int, c_int]),
     "vq_control_reset": (c_int, [c_void_p, c_void_p]),
     "vq_codebook_prep": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vq_search": (c_int, [c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_float,
-                          c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                          c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                          c_void_p]),
     "vq_search_exact": (c_int, [c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_void_p, c_int, c_float, c_int64,
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vq_gather_st": (c_int, [c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p,

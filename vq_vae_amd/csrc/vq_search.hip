@@ -48,6 +48,12 @@ struct SearchArgs {
   // pairwise mode (z := E): skip the pair (n, n); per-workgroup partials of sum/min/max
   double* pw_sum;
   float* pw_minmax;
+  // codebook split for small batches: blockIdx.y sweeps stages [y*sps, y*sps + sps) and leaves
+  // its per-row winner in part_d / part_i [ksplit][N]; a merge kernel picks the overall winner
+  int ksplit;
+  int stages_per_split;
+  float* part_d;
+  int32_t* part_i;
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -127,10 +133,22 @@ __global__ __launch_bounds__(512 / CT, 2 / CT) void vq_search_mfma_kernel(Search
   const int j = lane & 31, h = lane >> 5;
   const int64_t row0 = (int64_t)blockIdx.x * VQ_WG_ROWS + wave * (32 * CT);
 
+  const bool split = a.ksplit > 1;
+  const int st0 = blockIdx.y * a.stages_per_split;                 // first stage of this block
+  const int nst = (a.nstages - st0) < a.stages_per_split ? (a.nstages - st0) : a.stages_per_split;
+  const float* image = a.image + (size_t)st0 * STAGE_F;
+
   // A non-finite codebook sends every row to the exact kernel.
   if (a.control[VQ_CTL_CB_FLAG] != 0) {
-    if (threadIdx.x == 0 && a.loss_partial) a.loss_partial[blockIdx.x] = 0.0f;
-    if (h == 0) {
+    if (threadIdx.x == 0 && a.loss_partial && !split) a.loss_partial[blockIdx.x] = 0.0f;
+    if (split && h == 0) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const int64_t n = row0 + ct * 32 + j;
+        if (n < a.N) a.part_i[(size_t)blockIdx.y * a.N + n] = -1;
+      }
+    }
+    if (h == 0 && blockIdx.y == 0) {
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
         const int64_t n = row0 + ct * 32 + j;
@@ -141,7 +159,7 @@ __global__ __launch_bounds__(512 / CT, 2 / CT) void vq_search_mfma_kernel(Search
   }
 
   // Prologue DMA of stage 0 goes out first; it lands while z is being loaded.
-  stage_copy<D, NW>(a.image, 0, lds, wave, lane);
+  stage_copy<D, NW>(image, 0, lds, wave, lane);
 
   // ---- z tile into registers, in B-operand order: zr[ct][s] = z[row][2s + h] -----------
   float zr[CT][S];
@@ -184,7 +202,7 @@ __global__ __launch_bounds__(512 / CT, 2 / CT) void vq_search_mfma_kernel(Search
     asm volatile("" : "+v"(zoff[ct]));
   }
   asm volatile("" : "+s"(zstride));
-  if (!PAIRWISE) {
+  if (!PAIRWISE && blockIdx.y == 0) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
       const uint32_t o = (uint32_t)__shfl_xor((int)zmax_bits, off);
@@ -224,9 +242,9 @@ __global__ __launch_bounds__(512 / CT, 2 / CT) void vq_search_mfma_kernel(Search
   __syncthreads();  // stage 0 has landed (the barrier waits for this wave's DMA first)
 
   int cur = 0;
-  for (int st = 0; st < a.nstages; ++st) {
+  for (int st = 0; st < nst; ++st) {
     float* buf = lds + cur * STAGE_F;
-    if (st + 1 < a.nstages) stage_copy<D, NW>(a.image, st + 1, lds + (cur ^ 1) * STAGE_F, wave, lane);
+    if (st + 1 < nst) stage_copy<D, NW>(image, st + 1, lds + (cur ^ 1) * STAGE_F, wave, lane);
 
     const f32x4* A = reinterpret_cast<const f32x4*>(buf) + lane;
     const f32x4* e2s = reinterpret_cast<const f32x4*>(buf + VQ_STAGE_CODES * D) + h;
@@ -250,7 +268,7 @@ __global__ __launch_bounds__(512 / CT, 2 / CT) void vq_search_mfma_kernel(Search
       }
     }
     {
-      const int code0 = (st - 1) * VQ_STAGE_CODES + 32;
+      const int code0 = (st0 + st - 1) * VQ_STAGE_CODES + 32;
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)
         scan_tile<TEMP, PAIRWISE>(cB[ct], e2B, z2[ct], code0, a.T, self_code[ct], best[ct], bidx[ct], psum[ct],
@@ -279,7 +297,7 @@ __global__ __launch_bounds__(512 / CT, 2 / CT) void vq_search_mfma_kernel(Search
       f32x4 e2A[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) e2A[q] = e2s[2 * q];
-      const int code0 = st * VQ_STAGE_CODES;
+      const int code0 = (st0 + st) * VQ_STAGE_CODES;
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)
         scan_tile<TEMP, PAIRWISE>(cA[ct], e2A, z2[ct], code0, a.T, self_code[ct], best[ct], bidx[ct], psum[ct],
@@ -293,7 +311,7 @@ __global__ __launch_bounds__(512 / CT, 2 / CT) void vq_search_mfma_kernel(Search
     cur ^= 1;
   }
   {
-    const int code0 = (a.nstages - 1) * VQ_STAGE_CODES + 32;
+    const int code0 = (st0 + nst - 1) * VQ_STAGE_CODES + 32;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
       scan_tile<TEMP, PAIRWISE>(cB[ct], e2B, z2[ct], code0, a.T, self_code[ct], best[ct], bidx[ct], psum[ct],
@@ -317,7 +335,13 @@ __global__ __launch_bounds__(512 / CT, 2 / CT) void vq_search_mfma_kernel(Search
     const bool finite = z2[ct] <= VQ_NORM_LIMIT;  // false for NaN
     const bool ok = valid && finite;
     if (h == 0) {
-      if (ok) {
+      if (split) {
+        if (valid) {
+          a.part_d[(size_t)blockIdx.y * a.N + n] = b;
+          a.part_i[(size_t)blockIdx.y * a.N + n] = ok ? (int32_t)(bi + a.code_base) : -1;
+          if (!ok && blockIdx.y == 0) a.nf_rows[atomicAdd(&a.control[VQ_CTL_NF_COUNT], 1)] = (int32_t)n;
+        }
+      } else if (ok) {
         if (a.idx64) a.idx64[n] = (int64_t)bi + a.code_base;
         if (a.idx32) a.idx32[n] = (int32_t)(bi + a.code_base);
         if (a.dmin) a.dmin[n] = b;
@@ -601,7 +625,29 @@ __global__ __launch_bounds__(256) void vq_prep_norms_kernel(const float* __restr
   }
 }
 
-// Standalone gather + straight-through + loss partials for given int64 indices.
+// Merge of the codebook split: splits are in increasing code order, so "later split wins only
+// if strictly smaller" keeps the lowest index.  Flagged rows (index -1) are left to the exact kernel.
+__global__ __launch_bounds__(256) void vq_split_merge_kernel(const float* __restrict__ part_d,
+                                                            const int32_t* __restrict__ part_i, int ksplit, int64_t N,
+                                                            int64_t* __restrict__ idx64, int32_t* __restrict__ idx32,
+                                                            float* __restrict__ dmin) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float best = part_d[n];
+  int32_t bi = part_i[n];
+  if (bi >= 0) {
+    for (int y = 1; y < ksplit; ++y) {
+      const float d = part_d[(size_t)y * N + n];
+      if (d < best) { best = d; bi = part_i[(size_t)y * N + n]; }
+    }
+  }
+  if (idx64) idx64[n] = bi;
+  if (idx32) idx32[n] = bi;
+  if (dmin && bi >= 0) dmin[n] = best;
+}
+
+// Standalone gather + straight-through + loss partials for given int64 indices.  Rows whose
+// index is outside [0, K) are skipped (no output, no loss contribution).
 __global__ __launch_bounds__(256) void vq_gather_st_kernel(const float* __restrict__ z, int nchw, int64_t N, int D,
                                                            int64_t HW, const float* __restrict__ E, int K,
                                                            const int64_t* __restrict__ idx, float* __restrict__ q_out,
@@ -615,9 +661,8 @@ __global__ __launch_bounds__(256) void vq_gather_st_kernel(const float* __restri
   float part = 0.0f;
   if (nchw) {
     const int64_t n = row0 + t;
-    if (n < N) {
-      int64_t k = idx[n];
-      if (k < 0 || k >= K) k = 0;
+    const int64_t k = n < N ? idx[n] : -1;
+    if (k >= 0 && k < K) {
       const float* e = E + (size_t)k * D;
       const int64_t b = n / HW, hw = n - b * HW;
       const int64_t off0 = b * D * HW + hw;
@@ -632,8 +677,8 @@ __global__ __launch_bounds__(256) void vq_gather_st_kernel(const float* __restri
     for (int r = wave; r < VQ_WG_ROWS; r += 4) {
       const int64_t n = row0 + r;
       if (n >= N) break;
-      int64_t k = idx[n];
-      if (k < 0 || k >= K) k = 0;
+      const int64_t k = idx[n];
+      if (k < 0 || k >= K) continue;
       const float* e = E + (size_t)k * D;
       for (int c = lane; c < D; c += 64) {
         const float zv = z[n * D + c];
@@ -662,7 +707,7 @@ int launch_mfma(const SearchArgs& a, hipStream_t s) {
     attr_done[dev & 63] = true;
   }
   const int64_t blocks = (a.N + VQ_WG_ROWS - 1) / VQ_WG_ROWS;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512 / CT), lds_bytes, s, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)(a.ksplit > 1 ? a.ksplit : 1)), dim3(512 / CT), lds_bytes, s, a);
   return vq_hip_status(hipGetLastError());
 }
 
@@ -711,7 +756,28 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 }  // namespace
 
+// Codebook split for batches too small to fill the chip: at most 128 row tiles (32 Ki rows), so
+// that row tiles x splits stays within one round of 256 workgroups.
+struct SplitPlan { int ksplit; int sps; };
+SplitPlan split_plan(int64_t N, int K) {
+  const int64_t blocks = (N + VQ_WG_ROWS - 1) / VQ_WG_ROWS;
+  const int nstages = vq_kpad(K) / VQ_STAGE_CODES;
+  if (blocks > 128 || nstages < 8) return {1, nstages};
+  int ks = (int)(256 / blocks);
+  if (ks > nstages / 4) ks = nstages / 4;
+  if (ks > 64) ks = 64;
+  if (ks < 2) return {1, nstages};
+  const int sps = (nstages + ks - 1) / ks;
+  return {(nstages + sps - 1) / sps, sps};
+}
+
 extern "C" {
+
+size_t vq_search_split_bytes(int64_t N, int K) {
+  if (N <= 0 || K <= 0) return 0;
+  const SplitPlan p = split_plan(N, K);
+  return p.ksplit > 1 ? (size_t)p.ksplit * (size_t)N * 8 : 0;
+}
 
 size_t vq_image_bytes(int K, int D) {
   if (K <= 0 || D <= 0 || !vq_fast_dim(D)) return 256;
@@ -751,7 +817,7 @@ int vq_codebook_prep(const float* E, int K, int D, float* image, float* e2, int3
 static int search_common(const float* z, int layout, int64_t N, int D, int64_t HW, const float* E,
                          const float* image, const float* e2, int K, float temperature, int64_t code_base,
                          int64_t* idx64, int32_t* idx32, float* dmin, float* q_out, float* loss_partial,
-                         int32_t* nf_rows, int32_t* control, bool force_exact, hipStream_t s) {
+                         int32_t* nf_rows, int32_t* control, void* split_ws, bool force_exact, hipStream_t s) {
   if (!z || !E || !e2 || N <= 0 || K <= 0 || D <= 0) return VQ_ERR_INVALID_ARG;
   if (layout != VQ_LAYOUT_ND && layout != VQ_LAYOUT_NCHW) return VQ_ERR_INVALID_ARG;
   if (layout == VQ_LAYOUT_NCHW && (HW <= 0 || N % HW != 0)) return VQ_ERR_INVALID_ARG;
@@ -769,8 +835,34 @@ static int search_common(const float* z, int layout, int64_t N, int D, int64_t H
   const bool fast = !force_exact && vq_fast_dim(D) && image != nullptr && t_regular && aligned16(z) &&
                     aligned16(E) && aligned16(image) && idx32 != nullptr && nf_rows != nullptr && control != nullptr;
   if (fast) {
-    int rc = run_mfma(a, D, nchw, temperature != 1.0f, false, s);
-    if (rc != VQ_OK) return rc;
+    const SplitPlan sp = split_plan(N, K);
+    a.ksplit = 1;
+    a.stages_per_split = a.nstages;
+    int rc;
+    if (split_ws != nullptr && sp.ksplit > 1 && idx64 != nullptr) {
+      // small batch: split the codebook sweep over blockIdx.y, merge, then gather separately
+      a.ksplit = sp.ksplit;
+      a.stages_per_split = sp.sps;
+      a.part_d = static_cast<float*>(split_ws);
+      a.part_i = reinterpret_cast<int32_t*>(a.part_d + (size_t)sp.ksplit * N);
+      a.q_out = nullptr;
+      a.loss_partial = nullptr;
+      rc = run_mfma(a, D, nchw, temperature != 1.0f, false, s);
+      if (rc != VQ_OK) return rc;
+      hipLaunchKernelGGL(vq_split_merge_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, a.part_d, a.part_i,
+                         sp.ksplit, N, idx64, idx32, dmin);
+      if (q_out) {
+        hipLaunchKernelGGL(vq_gather_st_kernel, dim3((unsigned)blocks), dim3(256), 0, s, z, nchw ? 1 : 0, N, D, a.HW,
+                           E, K, idx64, q_out, loss_partial);
+      }
+      VQ_CHECK_HIP(hipGetLastError());
+      a.q_out = q_out;
+      a.loss_partial = loss_partial;
+      a.ksplit = 1;
+    } else {
+      rc = run_mfma(a, D, nchw, temperature != 1.0f, false, s);
+      if (rc != VQ_OK) return rc;
+    }
     // rows flagged by the MFMA kernel (normally none: the kernel then exits at once)
     float* fix_loss = loss_partial ? loss_partial + blocks : nullptr;
     return run_exact(a, D, nchw, true, fix_loss, VQ_FIX_WGS, s);
@@ -787,17 +879,18 @@ static int search_common(const float* z, int layout, int64_t N, int D, int64_t H
 
 int vq_search(const float* z, int layout, int64_t N, int D, int64_t HW, const float* E, const float* image,
               const float* e2, int K, float temperature, int64_t code_base, int64_t* idx64, int32_t* idx32,
-              float* dmin, float* q_out, float* loss_partial, int32_t* nf_rows, int32_t* control, void* stream) {
+              float* dmin, float* q_out, float* loss_partial, int32_t* nf_rows, int32_t* control, void* split_ws,
+              void* stream) {
   if (!idx32 || !nf_rows || !control) return VQ_ERR_INVALID_ARG;
   return search_common(z, layout, N, D, HW, E, image, e2, K, temperature, code_base, idx64, idx32, dmin, q_out,
-                       loss_partial, nf_rows, control, false, (hipStream_t)stream);
+                       loss_partial, nf_rows, control, split_ws, false, (hipStream_t)stream);
 }
 
 int vq_search_exact(const float* z, int layout, int64_t N, int D, int64_t HW, const float* E, const float* e2,
                     int K, float temperature, int64_t code_base, int64_t* idx64, int32_t* idx32, float* dmin,
                     float* q_out, float* loss_partial, void* stream) {
   return search_common(z, layout, N, D, HW, E, nullptr, e2, K, temperature, code_base, idx64, idx32, dmin, q_out,
-                       loss_partial, nullptr, nullptr, true, (hipStream_t)stream);
+                       loss_partial, nullptr, nullptr, nullptr, true, (hipStream_t)stream);
 }
 
 int vq_gather_st(const float* z, int layout, int64_t N, int D, int64_t HW, const float* E, int K,
@@ -820,6 +913,7 @@ int vq_pairwise_search_launch(const float* E, const float* image, const float* e
   a.nstages = vq_kpad(K) / VQ_STAGE_CODES; a.T = 1.0f; a.code_base = 0;
   a.idx64 = nn_idx; a.idx32 = idx32; a.dmin = nn_dist; a.q_out = nullptr; a.loss_partial = nullptr;
   a.nf_rows = nf_rows; a.control = control; a.pw_sum = sum_partial; a.pw_minmax = mm_partial;
+  a.ksplit = 1; a.stages_per_split = a.nstages;
   return run_mfma(a, D, false, false, true, (hipStream_t)stream);
 }
 

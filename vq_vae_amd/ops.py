@@ -101,7 +101,7 @@ def prepare_codebook(E: torch.Tensor, ws: Workspace):
 
 def search(z: torch.Tensor, E: torch.Tensor, ws: Workspace, temperature: float = 1.0, code_base: int = 0,
            want_quantized: bool = True, want_dmin: bool = False, exact: bool = False, prepared=None,
-           events=None):
+           events=None, allow_split: bool = True):
     """Nearest-codebook search (+ fused gather / straight-through / loss partials).
 
     Returns dict(indices int64 [N], idx32, dmin|None, quantized|None, loss_partial|None, n_partial).
@@ -125,11 +125,13 @@ def search(z: torch.Tensor, E: torch.Tensor, ws: Workspace, temperature: float =
                                   _ptr(idx64), _ptr(idx32), _ptr(dmin), _ptr(q), _ptr(lp), s), "vq_search_exact")
     else:
         nf_rows = ws.get("nf_rows", N * 4, torch.int32)
+        split_bytes = lib.vq_search_split_bytes(N, K) if allow_split else 0
+        split_ws = ws.get("split", split_bytes) if split_bytes else None
         if events is not None:
             events[0].record(torch.cuda.current_stream(dev))
         check(lib.vq_search(_ptr(z), layout, N, D, HW, _ptr(E), _ptr(image), _ptr(e2), K, float(temperature),
                             code_base, _ptr(idx64), _ptr(idx32), _ptr(dmin), _ptr(q), _ptr(lp), _ptr(nf_rows),
-                            _ptr(control), s), "vq_search")
+                            _ptr(control), _ptr(split_ws), s), "vq_search")
         if events is not None:
             events[1].record(torch.cuda.current_stream(dev))
     return {"indices": idx64, "idx32": idx32, "dmin": dmin, "quantized": q, "loss_partial": lp,
