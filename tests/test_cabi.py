@@ -129,3 +129,41 @@ def test_lazy_onehot_metadata():
     from vq_vae_amd import LazyOneHot
     lo = LazyOneHot(torch.tensor([3, 1, 2]), 8)
     assert lo.shape == (3, 8) and lo.dtype == torch.float32 and lo.dim() == 2 and lo.size(1) == 8
+
+
+def test_checkpoint_helpers_round_trip():
+    """A reference-shaped checkpoint (vqgan_state_dict with the quantize.* entries) loads into the
+    drop-in module; a row-sharded state reassembles to the same six tensors."""
+    from vq_vae_amd import EMAVectorQuantizer, checkpoint
+    torch.manual_seed(1)
+    src = EMAVectorQuantizer(100, 16, 3.0)
+    src.ema_cluster_size.uniform_(0, 3); src.ema_w.normal_(); src.usage_count.uniform_(0, 9)
+    src.last_reset_epoch.fill_(6)
+    model_state = {"encoder.conv.weight": torch.zeros(3), **{"quantize." + k: v for k, v in src.state_dict().items()}}
+    assert checkpoint.infer_shape(model_state) == (100, 16)
+    assert checkpoint.model_config(model_state) == {"vq_num_embed": 100, "vq_embed_dim": 16}
+    qs = checkpoint.quantizer_state(model_state)
+    assert list(qs.keys()) == list(src.state_dict().keys())
+    dst = EMAVectorQuantizer(100, 16, 3.0)
+    dst.load_state_dict(qs, strict=True)
+    assert torch.equal(dst.ema_w, src.ema_w) and float(dst.last_reset_epoch) == 6
+    shards = [checkpoint.shard_state(qs, r, 8) for r in range(8)]
+    assert sum(s["embedding.weight"].shape[0] for s in shards) == 100
+    merged = checkpoint.merge_shards(shards)
+    for k in qs:
+        assert torch.equal(merged[k], qs[k]), k
+    with pytest.raises(KeyError):
+        checkpoint.quantizer_state({"quantize.ema_w": torch.zeros(1)})
+
+
+def test_stats_json_schema():
+    from vq_vae_amd.stats import stats_to_json_dict
+    res = {"n_embed": 4, "unique_indices": np.array([0, 2]), "utilization": 0.5, "entropy": 1.0,
+           "normalized_entropy": 0.5, "gini": 0.0, "index_counts": np.array([3.0, 0, 3, 0]),
+           "probs": np.array([0.5, 0, 0.5, 0])}
+    d = stats_to_json_dict(res)
+    # key set and order of vqvae/codebook_utilization_check.py:208-217
+    assert list(d.keys()) == ["n_embed", "unique_indices", "utilization", "entropy", "normalized_entropy", "gini",
+                              "index_counts", "probs"]
+    import json
+    json.dumps(d)

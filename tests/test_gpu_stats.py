@@ -211,3 +211,27 @@ def test_data_parallel_hook_over_rccl_single_rank(dev):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_analyzer_front_end(dev, tmp_path):
+    """analyze_codebook_utilization over a stream of latent batches equals the statistics of the
+    oracle's indices for the concatenated batches; the module's state and mode are untouched."""
+    import json
+    from vq_vae_amd import EMAVectorQuantizer, stats
+    K, D = 512, 64
+    E = gauss(95, (K, D)) * np.float32(0.5)
+    m = EMAVectorQuantizer(K, D, 3.0).to(dev)
+    with torch.no_grad():
+        m.embedding.weight.copy_(torch.from_numpy(E))
+    m.train()
+    batches = [gauss(96 + i, (4, D, 16, 16)) for i in range(3)]
+    res = stats.analyze_codebook_utilization(m, (torch.from_numpy(b).to(dev) for b in batches), temperature=1.0)
+    assert m.training and float(m.usage_count.sum()) == 0          # eval-mode passes, no EMA update
+    idx = np.concatenate([vo.search(b, E)[0] for b in batches])
+    ref = numpy_index_stats(idx, K)
+    assert np.array_equal(res["index_counts"], ref["index_counts"])
+    assert res["utilization"] == ref["utilization"] and abs(res["entropy"] - ref["entropy"]) <= 1e-11 * ref["entropy"]
+    path = tmp_path / "codebook_stats.json"
+    stats.save_codebook_stats(res, str(path))
+    saved = json.loads(path.read_text())
+    assert saved["n_embed"] == K and len(saved["index_counts"]) == K and len(saved["probs"]) == K

@@ -102,8 +102,7 @@ def sharded_quantize_step(z: torch.Tensor, E_shard: torch.Tensor, ema_w_shard, c
     if training:
         slabs, _ = ops.embed_sums(ops._f32c(z, "latents"), idx32, K_loc, ws, code_base=code_base, zmax_valid=True)
         counts_loc = counts_full[code_base: code_base + K_loc].contiguous()
-        d, omd, eps, _ = ops.ema_scalars(K_total, decay, epsilon)
-        keps = ops.ema_scalars(K_total, decay, epsilon)[3]
+        d, omd, eps, keps = ops.ema_scalars(K_total, decay, epsilon)
         # cluster sizes: local EMA, global Laplace normaliser
         c = (counts_loc.to(torch.int64) & 0xFFFFFFFF).float()
         usage_shard += c

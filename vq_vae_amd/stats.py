@@ -99,3 +99,52 @@ def pairwise_codebook_stats(codebook: torch.Tensor, ws: Optional[ops.Workspace] 
                                 ops._ptr(control), ops._stream(E.device)), "vq_pairwise_stats")
     v = out.cpu().tolist()
     return {"nn_dist": nn_dist, "nn_idx": nn_idx, "min": v[0], "mean": v[1], "max": v[2]}
+
+
+@torch.no_grad()
+def analyze_codebook_utilization(quantizer, latent_batches, temperature: float = 1.0) -> dict:
+    """GPU counterpart of the reference's ``analyze_codebook_utilization``
+    (vqvae/codebook_utilization_check.py:64-120) for a stream of latent batches.
+
+    ``latent_batches`` yields the quantizer's inputs ((B, D, H, W) tensors, i.e. what
+    ``CustomVQGAN.encode`` returns).  The batches are quantized in eval mode (no EMA update, as
+    the reference's ``vqgan.eval()``) and the statistics come from the *index* output rather than
+    the one-hot matrix the reference's model forwards under the key "indices".  Returns the same
+    keys as the reference: n_embed, unique_indices, utilization, entropy, normalized_entropy,
+    gini, index_counts, probs.
+    """
+    was_training = quantizer.training
+    quantizer.eval()
+    acc = None
+    try:
+        for z in latent_batches:
+            _, _, (_, idx, _) = quantizer(z, temperature=temperature)
+            if acc is None:
+                acc = CodeUsage(quantizer.num_embeddings, idx.device)
+            acc.update(idx)
+    finally:
+        quantizer.train(was_training)
+    if acc is None:
+        raise ValueError("latent_batches was empty")
+    return acc.result()
+
+
+def stats_to_json_dict(results: dict) -> dict:
+    """The ``codebook_stats.json`` schema the reference writes with --save_details
+    (vqvae/codebook_utilization_check.py:208-217)."""
+    return {
+        "n_embed": int(results["n_embed"]),
+        "unique_indices": [int(v) for v in results["unique_indices"]],
+        "utilization": float(results["utilization"]),
+        "entropy": float(results["entropy"]),
+        "normalized_entropy": float(results["normalized_entropy"]),
+        "gini": float(results["gini"]),
+        "index_counts": [float(v) for v in results["index_counts"]],
+        "probs": [float(v) for v in results["probs"]],
+    }
+
+
+def save_codebook_stats(results: dict, path: str) -> None:
+    import json
+    with open(path, "w") as f:
+        json.dump(stats_to_json_dict(results), f, indent=2)
