@@ -284,3 +284,23 @@ def test_reference_init_collapse(dev, ops):
     assert rel_err(st["E"].cpu().numpy(), g["state_embedding_weight"]) <= TOL
     unused = g["state_usage_count"] == 0
     assert (st["E"].cpu().numpy()[unused] == 0).all()
+
+
+def test_documented_ctypes_binding(dev):
+    """The ctypes stub printed in the integration notes binds the library as shipped and returns
+    the oracle's indices (guards the document against drifting from the ABI)."""
+    import os, re
+    from conftest import ROOT
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = [b for b in re.findall(r"```python\n(.*?)```", text, re.S) if "def nearest_codes" in b][0]
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        ns = {}
+        exec(compile(block, "INTEGRATION.md", "exec"), ns)
+        z = gauss(301, (2, 64, 8, 8)); E = gauss(302, (512, 64))
+        idx = ns["nearest_codes"](torch.from_numpy(z).to(dev), torch.from_numpy(E).to(dev))
+        torch.cuda.synchronize()
+    finally:
+        os.chdir(cwd)
+    assert np.array_equal(idx.cpu().numpy(), vo.search(z, E)[0])
