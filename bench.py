@@ -12,7 +12,8 @@ torch.distributed.run, one rank per GPU, rows sharded data-parallel (weak scalin
 
 Prints ONE JSON line on rank 0 with the throughput, the roofline of the dominant kernel
 (HIP events around every search launch inside the timed region) and, at N = 1, a CPU
-baseline: the dense one-hot PyTorch formulation timed on the host cores on a bounded sample.
+baseline: the dense one-hot PyTorch formulation timed on the host cores on a bounded sample,
+and a parity gate (one training step on a 16 Ki-row sample against the C restatement).
 """
 from __future__ import annotations
 
@@ -56,6 +57,41 @@ def cpu_baseline(rows: int = 16384, reps: int = 3) -> dict:
                       f"{rows} vectors/step, median of {reps} steps ({med:.3f} s/step), torch {torch.__version__} CPU"}
 
 
+def parity_gate(z: torch.Tensor, E0: torch.Tensor, rows: int = 16384) -> dict:
+    """Correctness gate printed beside the throughput: one training step from a fresh EMA state
+    on the first `rows` latent vectors of the benchmark batch, on the GPU and through the
+    index-based C restatement (oracle/vq_oracle.c) on the host cores, which is timed as well."""
+    from oracle import vq_oracle as vo
+    from vq_vae_amd import ops
+    dev = z.device
+    zs = z[: rows // (H * W)].contiguous()
+    E = E0.clone()
+    ema_w = torch.zeros(K, D, device=dev); cs = torch.zeros(K, device=dev); usage = torch.zeros(K, device=dev)
+    out = ops.quantize_step(zs, E, ema_w, cs, usage, beta=BETA, decay=DECAY, epsilon=EPS, temperature=1.0,
+                            training=True, ws=ops.Workspace(dev))
+    torch.cuda.synchronize()
+    st = vo.OracleState.fresh(E0.cpu().numpy())
+    t0 = time.perf_counter()
+    ref = vo.forward(zs.cpu().numpy(), st, BETA, DECAY, EPS, 1.0, True)
+    t_cpu = time.perf_counter() - t0
+
+    def rel(a, b):
+        a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+        return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-30))
+
+    idx = out.indices.reshape(-1).cpu().numpy()
+    counts = (out.counts.cpu().numpy().astype(np.int64) & 0xFFFFFFFF)
+    return {"rows": int(idx.size), "index_mismatches": int((idx != ref["indices"].reshape(-1)).sum()),
+            "histogram_equal": bool(np.array_equal(counts, np.asarray(ref["counts"]).astype(np.int64))),
+            "max_rel_err": {"quantized": rel(out.quantized.cpu().numpy(), ref["quantized"]),
+                            "loss": rel(out.loss.item(), ref["loss"]),
+                            "perplexity": rel(out.perplexity.item(), ref["perplexity"]),
+                            "codebook": rel(E.cpu().numpy(), st.embedding), "ema_w": rel(ema_w.cpu().numpy(), st.ema_w),
+                            "cluster_size": rel(cs.cpu().numpy(), st.ema_cluster_size)},
+            "checker": f"index-based C restatement of the reference forward, OpenMP on the host cores: "
+                       f"{idx.size / t_cpu:.0f} vectors/s ({t_cpu:.2f} s for the sample)"}
+
+
 def measured_traffic(rows: int):
     """HBM bytes per launch of the search kernel from the committed rocprofv3 PMC passes
     (profiles/r1_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction), when the
@@ -81,6 +117,9 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=4 * 1024 * 1024, help="latent vectors per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--codebook", choices=["normal", "ref-init"], default="normal",
+                    help="normal: N(0,1) rows (high utilisation, the headline case); ref-init: the reference's "
+                         "U(-1/K, 1/K) initialisation, which collapses onto a few codes (skewed EMA scatter)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -110,6 +149,9 @@ def main() -> None:
     z = torch.randn(B, D, H, W, device=dev, generator=gz)
     ge = torch.Generator(device=dev).manual_seed(1)
     E = torch.randn(K, D, device=dev, generator=ge)
+    if args.codebook == "ref-init":
+        E = (torch.rand(K, D, device=dev, generator=ge) * 2 - 1) / K       # vqvae/ema_vector_quantizer.py:22
+    E0 = E.clone()
     ema_w = torch.zeros(K, D, device=dev)
     cs = torch.zeros(K, device=dev)
     usage = torch.zeros(K, device=dev)
@@ -166,7 +208,9 @@ def main() -> None:
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"fused quantize+EMA update, K={K}, D={D}, {rows} latent vectors per GPU as "
-                                   f"({B},{D},{H},{W}) NCHW fp32, N(0,1) latents and codebook, decay {DECAY}",
+                                   f"({B},{D},{H},{W}) NCHW fp32, N(0,1) latents, "
+                                   + ("N(0,1) codebook" if args.codebook == "normal" else "U(-1/K,1/K) codebook (skewed)")
+                                   + f", decay {DECAY}",
                        "rows_per_gpu": rows, "parallelism": f"dp{world}" if world > 1 else "single"},
             "roofline": {"bound": "mfma", "kernel": "vq_search_mfma_kernel<256,NCHW>", "achieved": achieved,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
@@ -177,6 +221,7 @@ def main() -> None:
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
+            line["parity"] = parity_gate(z, E0)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
