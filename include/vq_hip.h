@@ -88,6 +88,32 @@ int vq_search(const float* z, int layout, int64_t N, int D, int64_t HW, const fl
               float* dmin, float* q_out, float* loss_partial, int32_t* nf_rows, int32_t* control, void* split_ws,
               void* stream);
 
+/*
+ * Filtered search: the same outputs as vq_search -- the argmin of the fp32 distances of
+ * vqvae/ema_vector_quantizer.py:42-53 with the lowest index on ties, the gather (:58), the
+ * straight-through output (:95) and the loss partials (:92) -- computed in two steps: approximate
+ * distances from bf16-rounded operands on the bf16 matrix cores select, under a proven error
+ * bound, the few codes that can be the fp32 argmin; those are then evaluated with the exact fp32
+ * chain.  Rows the bound cannot settle go through the fp32 MFMA kernel (`image` of
+ * vq_codebook_prep), rows that are not finite through the exact kernel.  Supported for D in
+ * {64, 128, 256}, K <= 8192 per call and finite T > 0 (VQ_ERR_UNSUPPORTED otherwise; use
+ * vq_search).  q_out requires code_base == 0.
+ *   vq_filter_image_bytes(K, D)   bytes of the bf16 codebook image
+ *   vq_filter_work_bytes(N)       bytes of the candidate buffer `work`
+ *   vq_filter_loss_partial_bytes(N)  bytes of `loss_partial` (more partials than vq_search writes;
+ *                                 all of them are defined on return and feed vq_step_scalars)
+ *   vq_filter_prep                builds the bf16 image from E and the norms e2 of vq_codebook_prep
+ *                                 (call after it, on the same stream, whenever E changed)
+ */
+size_t vq_filter_image_bytes(int K, int D);
+size_t vq_filter_work_bytes(int64_t N);
+int vq_filter_prep(const float* E, const float* e2, int K, int D, void* fimage, void* stream);
+size_t vq_filter_loss_partial_bytes(int64_t N);
+int vq_search_filtered(const float* z, int layout, int64_t N, int D, int64_t HW, const float* E, const float* image,
+                       const float* e2, const void* fimage, int K, float temperature, int64_t code_base,
+                       int64_t* idx64, int32_t* idx32, float* dmin, float* q_out, float* loss_partial,
+                       int32_t* nf_rows, int32_t* control, void* work, void* stream);
+
 /* Same search through the exact scalar kernel only (any D <= 4096); used as the in-library
  * cross-check of the MFMA kernel and for shapes the MFMA kernel does not cover. */
 int vq_search_exact(const float* z, int layout, int64_t N, int D, int64_t HW, const float* E, const float* e2,

@@ -27,7 +27,7 @@ __host__ __device__ inline size_t vq_stage_floats(int D) { return (size_t)VQ_STA
 __host__ __device__ inline bool vq_fast_dim(int D) { return D == 16 || D == 32 || D == 64 || D == 128 || D == 256; }
 
 // Control words shared by the kernels of one step (device memory, 16 ints).
-enum { VQ_CTL_NF_COUNT = 0, VQ_CTL_CB_FLAG = 1, VQ_CTL_BAD_INDEX = 2, VQ_CTL_ZMAX = 3, VQ_CTL_WORDS = 16 };
+enum { VQ_CTL_NF_COUNT = 0, VQ_CTL_CB_FLAG = 1, VQ_CTL_BAD_INDEX = 2, VQ_CTL_ZMAX = 3, VQ_CTL_OVF_COUNT = 4, VQ_CTL_OVF2_COUNT = 5, VQ_CTL_WORDS = 16 };
 
 static inline int vq_hip_status(hipError_t e) { return e == hipSuccess ? VQ_OK : VQ_ERR_HIP_BASE + (int)e; }
 
@@ -82,3 +82,10 @@ static inline int vq_launch_absmax(const float* z, int64_t numel, int32_t* contr
 extern "C" int vq_pairwise_search_launch(const float* E, const float* image, const float* e2, int K, int D,
                                          float* nn_dist, int64_t* nn_idx, int32_t* idx32, double* sum_partial,
                                          float* mm_partial, int32_t* nf_rows, int32_t* control, void* stream);
+
+// Internal (not in the public header): bf16 filter + exact verification (vq_filter.hip).
+bool vq_filter_supported(int K, int D);
+extern "C" int vq_filter_verify_launch(const float* z, int nchw, int64_t N, int D, int64_t HW, const float* E,
+                                       const float* e2, const void* fimage, int K, float T, int64_t code_base,
+                                       int64_t* idx64, int32_t* idx32, float* dmin, int32_t* nf_rows,
+                                       int32_t** hard_rows_out, int32_t* control, void* work, void* stream);

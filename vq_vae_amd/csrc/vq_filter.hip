@@ -1,0 +1,570 @@
+// Filtered nearest-codebook search for gfx950 (MI355X): the same result as the fp32 search of
+// vq_search.hip -- the argmin of the fp32 fma-chain distances of
+// vqvae/ema_vector_quantizer.py:42-53, lowest index on ties -- at bf16 matrix-core speed.
+//
+//   1. Filter (vqf_filter_kernel).  Approximate distances a[n,k] = c_n + ||e_k||^2 - 2 z~.e~ from
+//      bf16-rounded operands on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate).  The same
+//      z-stationary layout as the fp32 kernel: latents in registers as the B operand, the bf16
+//      codebook image streamed through LDS by DMA, 16 approximate distances of one latent per lane.
+//      Each lane keeps the R smallest keys it has seen; a key is the distance with its low 12 bits
+//      replaced by the code's position, so a min / median-of-three pair keeps value and index at once.
+//   2. Verify (vqf_verify_kernel).  |a - (d + c_n)| <= delta_n is a rigorous bound (below), so only
+//      codes whose key lies within 2 delta_n (+ the key truncation) of the smallest key can be the
+//      fp32 argmin.  These few candidates are evaluated with the exact fp32 chain, in the order the
+//      fp32 MFMA and the CPU oracle use, and the smallest (lowest index on ties) wins.
+//   3. Rows whose candidate list may be incomplete (all R keys of a lane inside the band), rows
+//      that are not finite or degenerate, and every row of a non-finite codebook are handed to the
+//      exact scalar kernel through the same list the fp32 path uses.
+//
+// Error bound.  With z = z~ + dz and e = e~ + de (bf16 round-to-nearest),
+//   z.e - z~.e~ = z~.de + dz.e, so |2 z.e - 2 z~.e~| <= 2 (||z~|| ||de|| + ||dz|| ||e||)
+// by Cauchy-Schwarz; ||dz||, ||z~|| are computed per row from the actual rounding errors and
+// max ||de||, max ||e|| per codebook.  Products of two bf16 are exact in fp32; the fp32 accumulation
+// of the matrix core and the rounding of the fp32 chain itself are covered by (D + 16) 2^-21 times
+// the sum of the magnitudes.  ||e_k||^2 enters the contraction exactly, as three bf16 terms times
+// 1.0, and c_n >= ||z||^2 + delta_n (rounded up to bf16, times 1.0) keeps every a[n,k] positive, so
+// that keys order as unsigned/positive floats.
+#include "vq_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int FQ_STAGE_TILES = 4;            // 32-code tiles per LDS stage (128 codes)
+constexpr int FQ_WG_ROWS = 512;              // 8 waves x 2 column tiles x 32 latents
+constexpr uint32_t FQ_KEY_MASK = 0xFFFFF000u;  // 12 low bits carry (tile << 4) | register
+constexpr int FQ_MAX_TILES = 256;            // => K <= 8192 per launch
+constexpr float FQ_PAD_NORM = 1.0e38f;       // squared norm of padding codes (finite, and finite after adding c_n)
+constexpr float FQ_TINY_NORM = 1.0e-30f;     // rows with ||z||^2 below this take the exact kernel
+
+__device__ __forceinline__ uint32_t bf16_pair(float lo, float hi) {
+  bf16x2 v;
+  v[0] = (__bf16)lo;
+  v[1] = (__bf16)hi;
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float bf16_lo(uint32_t p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
+
+__host__ __device__ inline int fq_steps(int D) { return D / 16 + 1; }
+__host__ __device__ inline int fq_tiles(int K) { return (K + 32 * FQ_STAGE_TILES - 1) / (32 * FQ_STAGE_TILES) * FQ_STAGE_TILES; }
+
+// ---------------------------------------------------------------------------------------
+// bf16 codebook image: [tile][step][lane] fragments of 8 bf16.  Lane (i, g) of step s holds
+// -2 e~[32 tile + i][16 s + 8 g + 0..7]; the last step holds (e2_hi, e2_mid, e2_lo, 1, 0...) in
+// the g = 0 lanes.  hdr[0], hdr[1] = max ||e||^2, max ||e - e~||^2 (bit patterns, atomicMax).
+// ---------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(64) void vqf_prep_kernel(const float* __restrict__ E, const float* __restrict__ e2, int K,
+                                                      u32x4* __restrict__ image, uint32_t* __restrict__ hdr) {
+  constexpr int FS = D / 16 + 1;
+  const int lane = threadIdx.x, i = lane & 31, g = lane >> 5;
+  const int tile = blockIdx.x, code = tile * 32 + i;
+  const bool real = code < K;
+  const f32x4* row = reinterpret_cast<const f32x4*>(E + (size_t)(real ? code : 0) * D);
+  u32x4* dst = image + (size_t)tile * FS * 64 + lane;
+  float en = 0.0f, de = 0.0f;
+#pragma unroll
+  for (int s = 0; s < D / 16; ++s) {
+    f32x4 v0 = row[4 * s + 2 * g], v1 = row[4 * s + 2 * g + 1];
+    if (!real) { v0 = f32x4{0, 0, 0, 0}; v1 = f32x4{0, 0, 0, 0}; }
+    const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    u32x4 o;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const uint32_t w = bf16_pair(-2.0f * v[2 * p], -2.0f * v[2 * p + 1]);
+      o[p] = w;
+      const float r0 = v[2 * p] - (-0.5f * bf16_lo(w)), r1 = v[2 * p + 1] - (-0.5f * bf16_hi(w));
+      en = __builtin_fmaf(v[2 * p], v[2 * p], en);
+      en = __builtin_fmaf(v[2 * p + 1], v[2 * p + 1], en);
+      de = __builtin_fmaf(r0, r0, de);
+      de = __builtin_fmaf(r1, r1, de);
+    }
+    dst[s * 64] = o;
+  }
+  en += __shfl_xor(en, 32);
+  de += __shfl_xor(de, 32);
+  if (g == 0 && real) {
+    atomicMax(&hdr[0], __float_as_uint(en));
+    atomicMax(&hdr[1], __float_as_uint(de));
+  }
+  u32x4 o = u32x4{0, 0, 0, 0};
+  if (g == 0) {
+    float n2 = real ? e2[code] : FQ_PAD_NORM;
+    if (!(n2 <= FQ_PAD_NORM)) n2 = FQ_PAD_NORM;  // non-finite codebooks take the exact kernel anyway
+    const float hi = __uint_as_float(__float_as_uint(n2) & 0xffff0000u);
+    const float r1 = n2 - hi;
+    const float mid = __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+    const float lo = r1 - mid;
+    o[0] = bf16_pair(hi, mid);
+    o[1] = bf16_pair(lo, 1.0f);
+  }
+  dst[(D / 16) * 64] = o;
+}
+
+struct FilterArgs {
+  const float* z;
+  const u32x4* image;
+  const uint32_t* hdr;
+  int64_t N;
+  int64_t HW;
+  int nstages;
+  u32x4* cand;     // [rows][2][R/4] : the R smallest keys of each lane half (unused slots +inf)
+  float* band;     // [rows]
+  int32_t* control;
+  // list mode: the launch covers rows row_list[0 .. control[count_word]); cand / band are indexed
+  // by the position in the list
+  const int32_t* row_list;
+  int count_word;
+};
+
+template <int D>
+__device__ __forceinline__ void fq_stage_copy(const u32x4* image, int stage, char* lds_buf, int wave, int lane) {
+  constexpr int PIECES = FQ_STAGE_TILES * (D / 16 + 1);
+  const char* src = reinterpret_cast<const char*>(image) + (size_t)stage * PIECES * 1024 + lane * 16;
+#pragma unroll
+  for (int i = 0; i < (PIECES + 7) / 8; ++i) {
+    const int p = i * 8 + wave;
+    if (p < PIECES) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)p * 1024),
+                                       (__attribute__((address_space(3))) void*)(lds_buf + p * 1024), 16, 0, 0);
+    }
+  }
+}
+
+// Insert the 16 keys of one finished accumulator tile into the lane's sorted R smallest.
+// Keys are positive floats, so the unsigned minimum and the float median-of-three agree on their
+// order; neither inserts a canonicalising move.  maskv holds FQ_KEY_MASK in a vector register so
+// that mask, merge and the scalar position fit one v_and_or_b32.
+template <int R>
+__device__ __forceinline__ void fq_scan(const f32x16& c, uint32_t tilebits, uint32_t maskv, float (&m)[R]) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    // no inline asm here: the compiler must see the read of the MFMA result to place the wait states
+    const uint32_t kb = (__float_as_uint(c[r]) & maskv) | (tilebits + r);
+    const float x = __uint_as_float(kb);
+    const uint32_t m0b = __float_as_uint(m[0]);
+    float nm[R];
+    nm[0] = __uint_as_float(kb < m0b ? kb : m0b);
+#pragma unroll
+    for (int i = 1; i < R; ++i) nm[i] = __builtin_amdgcn_fmed3f(m[i - 1], m[i], x);
+#pragma unroll
+    for (int i = 0; i < R; ++i) m[i] = nm[i];
+  }
+}
+
+// R (4 or 8) = keys kept per lane.  The first pass runs R = 4; rows whose list overflowed are
+// filtered again with R = 8 (list mode).
+template <int D, bool NCHW, int R>
+__global__ __launch_bounds__(512, 2) void vqf_filter_kernel(FilterArgs a) {
+  constexpr int ZS = D / 16, FS = ZS + 1;
+  constexpr int STAGE_B = FQ_STAGE_TILES * FS * 1024;
+  extern __shared__ __attribute__((aligned(16))) char flds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31, g = lane >> 5;
+  const int64_t row0 = (int64_t)blockIdx.x * FQ_WG_ROWS + wave * 64;
+  if (a.control[VQ_CTL_CB_FLAG] != 0) return;  // the verify kernel flags every row
+  const bool listed = a.row_list != nullptr;
+  int64_t nrows = a.N;
+  if (listed) {
+    nrows = a.control[a.count_word];
+    if (nrows * 8 > a.N) return;  // too many unsettled rows: the fp32 kernel redoes the batch
+  }
+  if ((int64_t)blockIdx.x * FQ_WG_ROWS >= nrows) return;  // list mode: the grid covers the worst case
+
+  fq_stage_copy<D>(a.image, 0, flds, wave, lane);
+
+  const float emax = __builtin_sqrtf(__uint_as_float(a.hdr[0])) * 1.0001f;
+  const float demax = __builtin_sqrtf(__uint_as_float(a.hdr[1])) * 1.0001f;
+
+  u32x4 zb[2][FS];
+  float band[2];
+  uint32_t zmax_bits = 0;
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    int64_t n = row0 + ct * 32 + j;
+    if (n >= nrows) n = nrows - 1;
+    if (listed) n = a.row_list[n];
+    float zt2 = 0.0f, dz2 = 0.0f;
+    uint32_t am = 0;
+#pragma unroll
+    for (int s = 0; s < ZS; ++s) {
+      float v[8];
+      if (NCHW) {
+        const int64_t b = n / a.HW, hw = n - b * a.HW;
+        const float* src = a.z + (b * D + 16 * s + 8 * g) * a.HW + hw;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = src[(int64_t)i * a.HW];
+      } else {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.z + n * D + 16 * s + 8 * g);
+        const f32x4 x0 = src[0], x1 = src[1];
+        v[0] = x0[0]; v[1] = x0[1]; v[2] = x0[2]; v[3] = x0[3];
+        v[4] = x1[0]; v[5] = x1[1]; v[6] = x1[2]; v[7] = x1[3];
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const uint32_t w = bf16_pair(v[2 * p], v[2 * p + 1]);
+        zb[ct][s][p] = w;
+        const float t0 = bf16_lo(w), t1 = bf16_hi(w);
+        const float r0 = v[2 * p] - t0, r1 = v[2 * p + 1] - t1;
+        zt2 = __builtin_fmaf(t0, t0, zt2);
+        zt2 = __builtin_fmaf(t1, t1, zt2);
+        dz2 = __builtin_fmaf(r0, r0, dz2);
+        dz2 = __builtin_fmaf(r1, r1, dz2);
+        const uint32_t a0 = __float_as_uint(v[2 * p]) & 0x7fffffffu, a1 = __float_as_uint(v[2 * p + 1]) & 0x7fffffffu;
+        am = a0 > am ? a0 : am;
+        am = a1 > am ? a1 : am;
+      }
+    }
+    zmax_bits = am > zmax_bits ? am : zmax_bits;
+    zt2 += __shfl_xor(zt2, 32);
+    dz2 += __shfl_xor(dz2, 32);
+    // rigorous half-width of |a - (d + c)| for this row (see the file comment)
+    const float nz = __builtin_sqrtf(zt2) * 1.0001f, ndz = __builtin_sqrtf(dz2) * 1.0001f;
+    const float zc = nz + ndz;                                   // >= ||z||
+    const float delta0 = 2.0f * (nz * demax + ndz * emax) * 1.0001f + 1.0e-30f + nz * 1.0e-35f;
+    const float mag = 2.0f * (zc + emax) * (zc + emax) + delta0;  // >= sum of magnitudes in either evaluation
+    const float delta = delta0 + mag * ((float)(D + 16) * 4.76837158203125e-07f) * 1.01f;
+    band[ct] = 2.0f * delta * 1.0001f;
+    const float cshift = zc * zc * 1.0001f + delta;
+    const float cup = __uint_as_float((__float_as_uint(cshift) + 0xffffu) & 0xffff0000u);  // bf16, rounded up
+    u32x4 extra = u32x4{0, 0, 0, 0};
+    if (g == 0) {
+      extra[0] = bf16_pair(1.0f, 1.0f);
+      extra[1] = bf16_pair(1.0f, cup);
+    }
+    zb[ct][ZS] = extra;
+  }
+  {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const uint32_t o = (uint32_t)__shfl_xor((int)zmax_bits, off);
+      zmax_bits = o > zmax_bits ? o : zmax_bits;
+    }
+    if (lane == 0 && zmax_bits) atomicMax(reinterpret_cast<unsigned int*>(&a.control[VQ_CTL_ZMAX]), zmax_bits);
+  }
+
+  uint32_t maskv = FQ_KEY_MASK;
+  asm volatile("" : "+v"(maskv));
+  float m[2][R];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int i = 0; i < R; ++i) m[ct][i] = __builtin_inff();
+
+  __syncthreads();  // stage 0 has landed
+
+  int cur = 0;
+  for (int st = 0; st < a.nstages; ++st) {
+    char* buf = flds + cur * STAGE_B;
+    if (st + 1 < a.nstages) fq_stage_copy<D>(a.image, st + 1, flds + (cur ^ 1) * STAGE_B, wave, lane);
+    const u32x4* A = reinterpret_cast<const u32x4*>(buf) + lane;
+#pragma unroll
+    for (int t = 0; t < FQ_STAGE_TILES; ++t) {
+      f32x16 c0, c1;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { c0[i] = 0.0f; c1[i] = 0.0f; }
+#pragma unroll
+      for (int s = 0; s < FS; ++s) {
+#ifdef VQF_ABLATE_LDS
+        const bf16x8 af = __builtin_bit_cast(bf16x8, zb[1][(s + t) % FS]);
+#else
+        const bf16x8 af = __builtin_bit_cast(bf16x8, A[(t * FS + s) * 64]);
+#endif
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, zb[0][s]), c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, zb[1][s]), c1, 0, 0, 0);
+      }
+      const uint32_t tilebits = (uint32_t)(st * FQ_STAGE_TILES + t) << 4;
+#ifdef VQF_ABLATE_SCAN
+      m[0][0] = __builtin_fminf(m[0][0], c0[0] + c0[5]);
+      m[1][0] = __builtin_fminf(m[1][0], c1[0] + c1[5]);
+#else
+      fq_scan<R>(c0, tilebits, maskv, m[0]);
+      fq_scan<R>(c1, tilebits, maskv, m[1]);
+#endif
+    }
+    __syncthreads();  // every wave is done with buf; the DMA of stage st+1 has landed
+    cur ^= 1;
+  }
+
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int64_t pos = row0 + ct * 32 + j;   // cand / band are indexed by position (= row unless listed)
+    if (pos < nrows) {
+#pragma unroll
+      for (int q = 0; q < R / 4; ++q)
+        a.cand[(pos * 2 + g) * (R / 4) + q] = u32x4{__float_as_uint(m[ct][4 * q]), __float_as_uint(m[ct][4 * q + 1]),
+                                                   __float_as_uint(m[ct][4 * q + 2]), __float_as_uint(m[ct][4 * q + 3])};
+      if (g == 0) a.band[pos] = band[ct];
+    }
+  }
+}
+
+struct VerifyArgs {
+  const float* z;
+  const float* E;
+  const float* e2;
+  const u32x4* cand;
+  const float* band;
+  int64_t N;
+  int64_t HW;
+  int K;
+  int D;
+  float T;
+  int64_t code_base;
+  int64_t* idx64;
+  int32_t* idx32;
+  float* dmin;
+  int32_t* nf_rows;    // rows for the exact scalar kernel (not finite, degenerate, flagged codebook)
+  int32_t* ovf_rows;   // finite rows whose candidate list may be incomplete: next level
+  int ovf_word;        // control word counting ovf_rows
+  int32_t* control;
+  const int32_t* row_list;  // list mode (see FilterArgs)
+  int count_word;
+};
+
+__device__ __forceinline__ int fq_decode(uint32_t key, int g) {
+  const int r = key & 15, tile = (key >> 4) & 255;
+  return tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+}
+
+// One thread per row: exact fp32 chain distances of the surviving candidates.  Slot 0 is the
+// code of the smallest key (always a candidate); the other slots are evaluated under the lane's
+// own predicate, so that codes outside the band cost no memory traffic.
+template <bool NCHW, int R>
+__global__ __launch_bounds__(256) void vqf_verify_kernel(VerifyArgs a) {
+  constexpr int SL = 2 * (R - 1);  // candidate slots: R-1 per lane half (the R-th in band = overflow)
+  const int64_t pos = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool listed = a.row_list != nullptr;
+  if (listed && (int64_t)a.control[a.count_word] * 8 > a.N) return;  // the fp32 kernel redoes the batch
+  if (pos >= (listed ? (int64_t)a.control[a.count_word] : a.N)) return;
+  const int64_t n = listed ? (int64_t)a.row_list[pos] : pos;
+  bool exact_row = a.control[VQ_CTL_CB_FLAG] != 0;
+  bool overflow = false;
+  uint32_t kh[2][R];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int q = 0; q < R / 4; ++q) {
+      const u32x4 v = a.cand[(pos * 2 + g) * (R / 4) + q];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) kh[g][4 * q + i] = v[i];
+    }
+  const float band = a.band[pos];
+  const float v0 = __uint_as_float(kh[0][0] & FQ_KEY_MASK), v1 = __uint_as_float(kh[1][0] & FQ_KEY_MASK);
+  const int g0 = v1 < v0 ? 1 : 0;                 // half that holds the smallest key
+  const float mn = g0 ? v1 : v0;
+  const float thr = mn * 1.0009765625f + band;    // key truncation: value in (a (1 - 2^-11), a]
+  if (!(thr < __builtin_inff()) || !(mn >= 0.0f)) exact_row = true;  // also catches NaN
+  int code[SL];
+  bool ok[SL];
+  // slot order: (best half, 0), (other half, 0), (best half, 1), (other half, 1), ...
+#pragma unroll
+  for (int i = 0; i < R - 1; ++i)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int g = q ? 1 - g0 : g0;
+      const uint32_t key = g ? kh[1][i] : kh[0][i];
+      const int c = fq_decode(key, g);
+      code[2 * i + q] = c;
+      ok[2 * i + q] = __uint_as_float(key & FQ_KEY_MASK) <= thr && c < a.K;
+    }
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+    if (__uint_as_float(kh[g][R - 1] & FQ_KEY_MASK) <= thr) overflow = true;  // the list may be incomplete
+  if (!ok[0]) exact_row = true;
+  if (exact_row || overflow) {
+#pragma unroll
+    for (int s = 0; s < SL; ++s) { ok[s] = false; code[s] = 0; }
+    ok[0] = true;  // keeps the row's z pass (needed for the norm test) on a valid address
+  }
+
+  float acc[SL];
+#pragma unroll
+  for (int s = 0; s < SL; ++s) acc[s] = 0.0f;
+  float pe = 0.0f, po = 0.0f;
+  const float* zrow;
+  int64_t zst;
+  if (NCHW) { const int64_t b = n / a.HW, hw = n - b * a.HW; zrow = a.z + b * a.D * a.HW + hw; zst = a.HW; }
+  else { zrow = a.z + n * a.D; zst = 1; }
+  const f32x4* erow[SL];
+#pragma unroll
+  for (int s = 0; s < SL; ++s) erow[s] = reinterpret_cast<const f32x4*>(a.E + (size_t)code[s] * a.D);
+  // 16 channels per step: a lane's four 16-byte reads of a code row are issued back to back, so
+  // the 64-byte sector fetched by the first serves the other three (rows of different lanes share
+  // nothing, so a sector used once would cost four times the traffic).
+  for (int c16 = 0; c16 < a.D / 16; ++c16) {
+    float zv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) zv[i] = zrow[(int64_t)(16 * c16 + i) * zst];
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+      pe = __builtin_fmaf(zv[i], zv[i], pe);
+      po = __builtin_fmaf(zv[i + 1], zv[i + 1], po);
+    }
+    {
+      f32x4 e[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) e[q] = erow[0][4 * c16 + q];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[0] = __builtin_fmaf(zv[i], e[i >> 2][i & 3], acc[0]);
+    }
+#pragma unroll
+    for (int s = 1; s < SL; ++s) {
+      if (ok[s]) {
+        f32x4 e[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e[q] = erow[s][4 * c16 + q];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[s] = __builtin_fmaf(zv[i], e[i >> 2][i & 3], acc[s]);
+      }
+    }
+  }
+  const float z2 = pe + po;
+  if (!(z2 <= VQ_NORM_LIMIT) || z2 < FQ_TINY_NORM) exact_row = true;
+  float best = __builtin_inff();
+  int bi = 0x7fffffff;
+#pragma unroll
+  for (int s = 0; s < SL; ++s) {
+    float d = __builtin_fmaf(-2.0f, acc[s], z2 + a.e2[code[s]]);
+    if (a.T != 1.0f) d = d / a.T;
+    const bool take = ok[s] && (d < best || (d == best && code[s] < bi));
+    best = take ? d : best;
+    bi = take ? code[s] : bi;
+  }
+  if (exact_row || overflow) {
+    // -2: the exact kernel's row, -1: next level's row (the gather skips both)
+    if (a.idx64) a.idx64[n] = exact_row ? -2 : -1;
+    a.idx32[n] = exact_row ? -2 : -1;
+    if (exact_row) a.nf_rows[atomicAdd(&a.control[VQ_CTL_NF_COUNT], 1)] = (int32_t)n;
+    else a.ovf_rows[atomicAdd(&a.control[a.ovf_word], 1)] = (int32_t)n;
+  } else {
+    if (a.idx64) a.idx64[n] = (int64_t)bi + a.code_base;
+    a.idx32[n] = (int32_t)(bi + a.code_base);
+    if (a.dmin) a.dmin[n] = best;
+  }
+}
+
+template <int D, bool NCHW, int R>
+int launch_filter(const FilterArgs& a, hipStream_t s) {
+  constexpr int STAGE_B = FQ_STAGE_TILES * (D / 16 + 1) * 1024;
+  const size_t lds_bytes = 2 * STAGE_B;
+  auto kern = vqf_filter_kernel<D, NCHW, R>;
+  static bool attr_done[64] = {};
+  int dev = 0;
+  VQ_CHECK_HIP(hipGetDevice(&dev));
+  if (!attr_done[dev & 63]) {
+    VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds_bytes));
+    attr_done[dev & 63] = true;
+  }
+  const int64_t blocks = (a.N + FQ_WG_ROWS - 1) / FQ_WG_ROWS;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds_bytes, s, a);
+  return vq_hip_status(hipGetLastError());
+}
+
+template <int R>
+int dispatch_filter(const FilterArgs& f, int D, bool nchw, hipStream_t s) {
+  switch (D) {
+    case 64: return nchw ? launch_filter<64, true, R>(f, s) : launch_filter<64, false, R>(f, s);
+    case 128: return nchw ? launch_filter<128, true, R>(f, s) : launch_filter<128, false, R>(f, s);
+    default: return nchw ? launch_filter<256, true, R>(f, s) : launch_filter<256, false, R>(f, s);
+  }
+}
+
+template <int R>
+int launch_verify(const VerifyArgs& v, bool nchw, hipStream_t s) {
+  const unsigned vb = (unsigned)((v.N + 255) / 256);
+  if (nchw) hipLaunchKernelGGL((vqf_verify_kernel<true, R>), dim3(vb), dim3(256), 0, s, v);
+  else hipLaunchKernelGGL((vqf_verify_kernel<false, R>), dim3(vb), dim3(256), 0, s, v);
+  return vq_hip_status(hipGetLastError());
+}
+
+}  // namespace
+
+bool vq_filter_supported(int K, int D) { return (D == 64 || D == 128 || D == 256) && K > 0 && fq_tiles(K) <= FQ_MAX_TILES; }
+
+extern "C" {
+
+size_t vq_filter_image_bytes(int K, int D) {
+  if (!vq_filter_supported(K, D)) return 256;
+  return (size_t)fq_tiles(K) * fq_steps(D) * 1024 + 256;
+}
+
+
+int vq_filter_prep(const float* E, const float* e2, int K, int D, void* fimage, void* stream) {
+  if (!E || !e2 || !fimage) return VQ_ERR_INVALID_ARG;
+  if (!vq_filter_supported(K, D)) return VQ_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const int tiles = fq_tiles(K);
+  u32x4* image = static_cast<u32x4*>(fimage);
+  uint32_t* hdr = reinterpret_cast<uint32_t*>(static_cast<char*>(fimage) + (size_t)tiles * fq_steps(D) * 1024);
+  VQ_CHECK_HIP(hipMemsetAsync(hdr, 0, 256, s));
+  switch (D) {
+    case 64: hipLaunchKernelGGL(vqf_prep_kernel<64>, dim3(tiles), dim3(64), 0, s, E, e2, K, image, hdr); break;
+    case 128: hipLaunchKernelGGL(vqf_prep_kernel<128>, dim3(tiles), dim3(64), 0, s, E, e2, K, image, hdr); break;
+    default: hipLaunchKernelGGL(vqf_prep_kernel<256>, dim3(tiles), dim3(64), 0, s, E, e2, K, image, hdr); break;
+  }
+  return vq_hip_status(hipGetLastError());
+}
+
+// Work buffer: [keys of pass 1: N x 32][band: N x 4][list A: N x 4][keys of pass 2: N x 64][band: N x 4][list B: N x 4]
+size_t vq_filter_work_bytes(int64_t N) { return N > 0 ? (size_t)N * 112 : 256; }
+
+// Internal (benchmarks): the first-pass filter kernel alone.
+int vq_filter_only_launch(const float* z, int nchw, int64_t N, int D, int64_t HW, const void* fimage, int K,
+                          int32_t* control, void* work, void* stream) {
+  const int tiles = fq_tiles(K);
+  FilterArgs f{};
+  f.z = z; f.image = static_cast<const u32x4*>(fimage);
+  f.hdr = reinterpret_cast<const uint32_t*>(static_cast<const char*>(fimage) + (size_t)tiles * fq_steps(D) * 1024);
+  f.N = N; f.HW = nchw ? HW : 1; f.nstages = tiles / FQ_STAGE_TILES;
+  f.cand = static_cast<u32x4*>(work);
+  f.band = reinterpret_cast<float*>(static_cast<char*>(work) + (size_t)N * 32);
+  f.control = control;
+  return dispatch_filter<4>(f, D, nchw != 0, (hipStream_t)stream);
+}
+
+// Internal: filter + verify, two levels.  Settled rows get idx / dmin; rows for the exact kernel
+// are appended to nf_rows (control[VQ_CTL_NF_COUNT]); rows that overflowed both levels are left
+// in *hard_rows_out (control[VQ_CTL_OVF2_COUNT]) for the per-row kernel.  Unsettled rows hold -1.
+int vq_filter_verify_launch(const float* z, int nchw, int64_t N, int D, int64_t HW, const float* E, const float* e2,
+                            const void* fimage, int K, float T, int64_t code_base, int64_t* idx64, int32_t* idx32,
+                            float* dmin, int32_t* nf_rows, int32_t** hard_rows_out, int32_t* control, void* work,
+                            void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int tiles = fq_tiles(K);
+  char* w = static_cast<char*>(work);
+  int32_t* listA = reinterpret_cast<int32_t*>(w + (size_t)N * 36);
+  int32_t* listB = reinterpret_cast<int32_t*>(w + (size_t)N * 108);
+  *hard_rows_out = listB;
+  FilterArgs f{};
+  f.z = z; f.image = static_cast<const u32x4*>(fimage);
+  f.hdr = reinterpret_cast<const uint32_t*>(static_cast<const char*>(fimage) + (size_t)tiles * fq_steps(D) * 1024);
+  f.N = N; f.HW = nchw ? HW : 1; f.nstages = tiles / FQ_STAGE_TILES;
+  f.cand = reinterpret_cast<u32x4*>(w);
+  f.band = reinterpret_cast<float*>(w + (size_t)N * 32);
+  f.control = control;
+  int rc = dispatch_filter<4>(f, D, nchw != 0, s);
+  if (rc != VQ_OK) return rc;
+  VerifyArgs v{};
+  v.z = z; v.E = E; v.e2 = e2; v.cand = f.cand; v.band = f.band; v.N = N; v.HW = f.HW; v.K = K; v.D = D; v.T = T;
+  v.code_base = code_base; v.idx64 = idx64; v.idx32 = idx32; v.dmin = dmin; v.nf_rows = nf_rows; v.control = control;
+  v.ovf_rows = listA; v.ovf_word = VQ_CTL_OVF_COUNT;
+  rc = launch_verify<4>(v, nchw != 0, s);
+  if (rc != VQ_OK) return rc;
+  // second level over list A: 8 keys per lane
+  f.cand = reinterpret_cast<u32x4*>(w + (size_t)N * 40);
+  f.band = reinterpret_cast<float*>(w + (size_t)N * 104);
+  f.row_list = listA; f.count_word = VQ_CTL_OVF_COUNT;
+  rc = dispatch_filter<8>(f, D, nchw != 0, s);
+  if (rc != VQ_OK) return rc;
+  v.cand = f.cand; v.band = f.band; v.row_list = listA; v.count_word = VQ_CTL_OVF_COUNT;
+  v.ovf_rows = listB; v.ovf_word = VQ_CTL_OVF2_COUNT;
+  return launch_verify<8>(v, nchw != 0, s);
+}
+
+}  // extern "C"

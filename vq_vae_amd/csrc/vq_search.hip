@@ -54,7 +54,17 @@ struct SearchArgs {
   int stages_per_split;
   float* part_d;
   int32_t* part_i;
+  // filtered search, fall-back role: run only if the first filter pass left more than N/8 rows
+  // unsettled (control[VQ_CTL_OVF_COUNT]); rows the verification already handed to the exact
+  // kernel (marked -2 in idx32) are skipped without a new list entry
+  int fallback_role;
 };
+
+// The filtered search gives up on a batch whose first pass left more than an eighth of the rows
+// unsettled (codes too close together for the bf16 filter): the fp32 kernel then redoes all rows.
+__device__ __forceinline__ bool vq_filter_gave_up(const int32_t* control, int64_t N) {
+  return (int64_t)control[VQ_CTL_OVF_COUNT] * 8 > N;
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -132,6 +142,8 @@ __global__ __launch_bounds__(512 / CT, 2 / CT) void vq_search_mfma_kernel(Search
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 31, h = lane >> 5;
   const int64_t row0 = (int64_t)blockIdx.x * VQ_WG_ROWS + wave * (32 * CT);
+
+  if (a.fallback_role && !vq_filter_gave_up(a.control, a.N)) return;
 
   const bool split = a.ksplit > 1;
   const int st0 = blockIdx.y * a.stages_per_split;                 // first stage of this block
@@ -332,7 +344,8 @@ __global__ __launch_bounds__(512 / CT, 2 / CT) void vq_search_mfma_kernel(Search
 
     const int64_t n = row0 + ct * 32 + j;
     const bool valid = n < a.N;
-    const bool finite = z2[ct] <= VQ_NORM_LIMIT;  // false for NaN
+    const bool finite = z2[ct] <= VQ_NORM_LIMIT &&  // false for NaN
+                        !(a.fallback_role && valid && a.idx32[n] == -2);
     const bool ok = valid && finite;
     if (h == 0) {
       if (split) {
@@ -345,7 +358,7 @@ __global__ __launch_bounds__(512 / CT, 2 / CT) void vq_search_mfma_kernel(Search
         if (a.idx64) a.idx64[n] = (int64_t)bi + a.code_base;
         if (a.idx32) a.idx32[n] = (int32_t)(bi + a.code_base);
         if (a.dmin) a.dmin[n] = b;
-      } else if (valid) {
+      } else if (valid && !a.fallback_role) {
         a.nf_rows[atomicAdd(&a.control[VQ_CTL_NF_COUNT], 1)] = (int32_t)n;
       }
     }
@@ -561,6 +574,107 @@ __global__ __launch_bounds__(256) void vq_search_exact_kernel(SearchArgs a, int 
 }
 
 // ---------------------------------------------------------------------------------------
+// One workgroup per listed row: exact fp32 distances to every code (finite rows only, D % 4 == 0,
+// D <= 1024).  Serves the few rows the filtered search cannot settle with its candidate lists;
+// the cost is ~K*D fma per row on the vector ALUs, so it only pays for short lists.
+// Thread t takes codes t, t + 256, ... four at a time; same fma chain as everywhere else.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vq_search_rows_kernel(SearchArgs a, int D, int nchw,
+                                                             const int32_t* __restrict__ list, int count_word,
+                                                             float* __restrict__ loss_out) {
+  __shared__ __attribute__((aligned(16))) float zs[1024];
+  __shared__ float rb[256];
+  __shared__ int ri[256];
+  __shared__ float z2s;
+  const int t = threadIdx.x;
+  const int count = vq_filter_gave_up(a.control, a.N) ? 0 : a.control[count_word];
+  float block_loss = 0.0f;  // meaningful in thread 0
+  for (int i = blockIdx.x; i < count; i += gridDim.x) {
+    const int64_t n = list[i];
+    __syncthreads();
+    for (int c = t; c < D; c += 256) zs[c] = z_load(a.z, nchw != 0, n, c, D, a.HW);
+    __syncthreads();
+    if (t < 2) {
+      float p = 0.0f;
+      for (int c = t; c < D; c += 2) p = __builtin_fmaf(zs[c], zs[c], p);
+      const float o = __shfl_xor(p, 1);
+      if (t == 0) z2s = p + o;
+    }
+    __syncthreads();
+    const float z2 = z2s;
+    float best = __builtin_inff();
+    int bi = 0x7fffffff;
+    for (int k0 = t; k0 < a.K; k0 += 1024) {
+      int kk[4];
+      const f32x4* er[4];
+      float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        kk[q] = k0 + 256 * q;
+        er[q] = reinterpret_cast<const f32x4*>(a.E + (size_t)(kk[q] < a.K ? kk[q] : k0) * D);
+      }
+#pragma unroll 4
+      for (int c4 = 0; c4 < D / 4; ++c4) {
+        const f32x4 zv = reinterpret_cast<const f32x4*>(zs)[c4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 e = er[q][c4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) acc[q] = __builtin_fmaf(zv[m], e[m], acc[q]);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (kk[q] < a.K) {
+          float d = __builtin_fmaf(-2.0f, acc[q], z2 + a.e2[kk[q]]);
+          if (a.T != 1.0f) d = d / a.T;
+          if (d < best) { best = d; bi = kk[q]; }  // codes visited in increasing order: '<' keeps the lowest index
+        }
+      }
+    }
+    rb[t] = best;
+    ri[t] = bi;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+      if (t < off) {
+        const float d2 = rb[t + off];
+        const int i2 = ri[t + off];
+        if (d2 < rb[t] || (d2 == rb[t] && i2 < ri[t])) { rb[t] = d2; ri[t] = i2; }
+      }
+      __syncthreads();
+    }
+    const int w = ri[0] == 0x7fffffff ? 0 : ri[0];
+    if (t == 0) {
+      if (a.idx64) a.idx64[n] = (int64_t)w + a.code_base;
+      if (a.idx32) a.idx32[n] = (int32_t)(w + a.code_base);
+      if (a.dmin) a.dmin[n] = rb[0];
+    }
+    if (a.q_out) {
+      const float* e = a.E + (size_t)w * D;
+      float part = 0.0f;
+      for (int c = t; c < D; c += 256) {
+        const float zv = zs[c];
+        const float diff = e[c] - zv;
+        part = __builtin_fmaf(diff, diff, part);
+        int64_t off;
+        if (nchw) { const int64_t b = n / a.HW, hw = n - b * a.HW; off = (b * D + c) * a.HW + hw; }
+        else off = n * D + c;
+        a.q_out[off] = zv + diff;
+      }
+      __syncthreads();
+      rb[t] = part;
+      __syncthreads();
+      for (int off = 128; off >= 1; off >>= 1) {
+        if (t < off) rb[t] += rb[t + off];
+        __syncthreads();
+      }
+      if (t == 0) block_loss += rb[0];
+    }
+  }
+  if (t == 0 && loss_out) loss_out[blockIdx.x] = block_loss;
+}
+
+// ---------------------------------------------------------------------------------------
 // Codebook preparation: squared norms + MFMA-fragment image.
 // One wave per 32-code tile; lane (i = lane&31, h = lane>>5) walks row i's channels 2s+h,
 // which is both the even/odd norm chain and the A-operand element order.
@@ -651,7 +765,8 @@ __global__ __launch_bounds__(256) void vq_split_merge_kernel(const float* __rest
 __global__ __launch_bounds__(256) void vq_gather_st_kernel(const float* __restrict__ z, int nchw, int64_t N, int D,
                                                            int64_t HW, const float* __restrict__ E, int K,
                                                            const int64_t* __restrict__ idx, float* __restrict__ q_out,
-                                                           float* __restrict__ loss_partial) {
+                                                           float* __restrict__ loss_partial,
+                                                           const int32_t* __restrict__ gate_control) {
   // A workgroup owns 256 consecutive rows.  NCHW: thread = row, loop over channels, so the
   // z loads and q stores of a wave are contiguous along hw; the codebook rows come through
   // the caches.  ND: a wave walks one row at a time, lanes along channels.
@@ -659,18 +774,42 @@ __global__ __launch_bounds__(256) void vq_gather_st_kernel(const float* __restri
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int64_t row0 = (int64_t)blockIdx.x * VQ_WG_ROWS;
   float part = 0.0f;
+  if (gate_control != nullptr && vq_filter_gave_up(gate_control, N)) {
+    // filtered search that fell back to the fp32 kernel: that kernel writes every row itself
+    if (t == 0 && loss_partial) loss_partial[blockIdx.x] = 0.0f;
+    return;
+  }
   if (nchw) {
     const int64_t n = row0 + t;
     const int64_t k = n < N ? idx[n] : -1;
     if (k >= 0 && k < K) {
-      const float* e = E + (size_t)k * D;
+      const f32x4* e = reinterpret_cast<const f32x4*>(E + (size_t)k * D);
       const int64_t b = n / HW, hw = n - b * HW;
       const int64_t off0 = b * D * HW + hw;
-      for (int c = 0; c < D; ++c) {
-        const float zv = z[off0 + (int64_t)c * HW];
-        const float diff = e[c] - zv;
-        part = __builtin_fmaf(diff, diff, part);
-        q_out[off0 + (int64_t)c * HW] = zv + diff;
+      if ((D & 15) == 0) {
+        // 16 channels per step: the four 16-byte reads of the code row hit one 64-byte sector
+        for (int c16 = 0; c16 < D / 16; ++c16) {
+          f32x4 ev[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) ev[q] = e[4 * c16 + q];
+          float zv[16];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) zv[i] = z[off0 + (int64_t)(16 * c16 + i) * HW];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const float diff = ev[i >> 2][i & 3] - zv[i];
+            part = __builtin_fmaf(diff, diff, part);
+            q_out[off0 + (int64_t)(16 * c16 + i) * HW] = zv[i] + diff;
+          }
+        }
+      } else {
+        const float* es = E + (size_t)k * D;
+        for (int c = 0; c < D; ++c) {
+          const float zv = z[off0 + (int64_t)c * HW];
+          const float diff = es[c] - zv;
+          part = __builtin_fmaf(diff, diff, part);
+          q_out[off0 + (int64_t)c * HW] = zv + diff;
+        }
       }
     }
   } else {
@@ -839,7 +978,7 @@ static int search_common(const float* z, int layout, int64_t N, int D, int64_t H
     a.ksplit = 1;
     a.stages_per_split = a.nstages;
     int rc;
-    if (split_ws != nullptr && sp.ksplit > 1 && idx64 != nullptr) {
+    if (split_ws != nullptr && sp.ksplit > 1 && idx64 != nullptr && (q_out == nullptr || code_base == 0)) {
       // small batch: split the codebook sweep over blockIdx.y, merge, then gather separately
       a.ksplit = sp.ksplit;
       a.stages_per_split = sp.sps;
@@ -853,7 +992,7 @@ static int search_common(const float* z, int layout, int64_t N, int D, int64_t H
                          sp.ksplit, N, idx64, idx32, dmin);
       if (q_out) {
         hipLaunchKernelGGL(vq_gather_st_kernel, dim3((unsigned)blocks), dim3(256), 0, s, z, nchw ? 1 : 0, N, D, a.HW,
-                           E, K, idx64, q_out, loss_partial);
+                           E, K, idx64, q_out, loss_partial, (const int32_t*)nullptr);
       }
       VQ_CHECK_HIP(hipGetLastError());
       a.q_out = q_out;
@@ -886,6 +1025,61 @@ int vq_search(const float* z, int layout, int64_t N, int D, int64_t HW, const fl
                        loss_partial, nf_rows, control, split_ws, false, (hipStream_t)stream);
 }
 
+// loss partials of the filtered search: [0, blocks) gather of the settled rows, [blocks, +FIX) exact kernel,
+// then [.., +blocks) fp32 kernel in the fall-back role, then [.., +FIX) per-row kernel
+size_t vq_filter_loss_partial_bytes(int64_t N) { return (size_t)(2 * vq_search_blocks(N) + 2 * VQ_FIX_WGS) * 4; }
+
+int vq_search_filtered(const float* z, int layout, int64_t N, int D, int64_t HW, const float* E, const float* image,
+                       const float* e2, const void* fimage, int K, float temperature, int64_t code_base,
+                       int64_t* idx64, int32_t* idx32, float* dmin, float* q_out, float* loss_partial,
+                       int32_t* nf_rows, int32_t* control, void* work, void* stream) {
+  if (!z || !E || !image || !e2 || !fimage || !idx64 || !idx32 || !nf_rows || !control || !work) return VQ_ERR_INVALID_ARG;
+  if (N <= 0 || K <= 0 || D <= 0) return VQ_ERR_INVALID_ARG;
+  if (layout != VQ_LAYOUT_ND && layout != VQ_LAYOUT_NCHW) return VQ_ERR_INVALID_ARG;
+  if (layout == VQ_LAYOUT_NCHW && (HW <= 0 || N % HW != 0)) return VQ_ERR_INVALID_ARG;
+  const bool t_regular = temperature > 0.0f && temperature < __builtin_inff();
+  if (!vq_filter_supported(K, D) || !t_regular || N >= (int64_t)1 << 31 || (int64_t)K + code_base >= (int64_t)1 << 31)
+    return VQ_ERR_UNSUPPORTED;
+  if (!aligned16(z) || !aligned16(E) || !aligned16(image) || !aligned16(fimage) || !aligned16(work)) return VQ_ERR_INVALID_ARG;
+  if (q_out != nullptr && code_base != 0) return VQ_ERR_UNSUPPORTED;  // the gather below indexes E by the global code
+  hipStream_t s = (hipStream_t)stream;
+  const bool nchw = layout == VQ_LAYOUT_NCHW;
+  const int64_t blocks = vq_search_blocks(N);
+  // 1. bf16 filter + exact verification of the candidates, two levels: settles almost every row
+  int32_t* hard_rows = nullptr;
+  int rc = vq_filter_verify_launch(z, nchw ? 1 : 0, N, D, HW, E, e2, fimage, K, temperature, code_base, idx64, idx32,
+                                   dmin, nf_rows, &hard_rows, control, work, stream);
+  if (rc != VQ_OK) return rc;
+  if (q_out) {
+    // 2. settled rows: gather + straight-through + loss partials (rows marked -1 are skipped)
+    hipLaunchKernelGGL(vq_gather_st_kernel, dim3((unsigned)blocks), dim3(256), 0, s, z, nchw ? 1 : 0, N, D,
+                       nchw ? HW : 1, E, K, idx64, q_out, loss_partial, (const int32_t*)control);
+    VQ_CHECK_HIP(hipGetLastError());
+  }
+  SearchArgs a{};
+  a.z = z; a.E = E; a.image = image; a.e2 = e2; a.N = N; a.HW = nchw ? HW : 1; a.K = K;
+  a.nstages = vq_kpad(K) / VQ_STAGE_CODES; a.T = temperature; a.code_base = code_base;
+  a.idx64 = idx64; a.idx32 = idx32; a.dmin = dmin; a.q_out = q_out;
+  a.nf_rows = nf_rows; a.control = control; a.ksplit = 1; a.stages_per_split = a.nstages;
+  // 3. the few rows with more close codes than both candidate lists hold: one workgroup per row
+  float* row_loss = loss_partial ? loss_partial + 2 * blocks + VQ_FIX_WGS : nullptr;
+  hipLaunchKernelGGL(vq_search_rows_kernel, dim3(VQ_FIX_WGS), dim3(256), 0, s, a, D, nchw ? 1 : 0,
+                     (const int32_t*)hard_rows, (int)VQ_CTL_OVF2_COUNT, row_loss);
+  VQ_CHECK_HIP(hipGetLastError());
+  // 4. fall-back: a batch the filter could not separate (over N/8 rows unsettled after the first
+  //    pass) is redone by the fp32 kernel; otherwise its workgroups exit at once
+  a.loss_partial = loss_partial ? loss_partial + blocks + VQ_FIX_WGS : nullptr;
+  if (a.loss_partial) VQ_CHECK_HIP(hipMemsetAsync(a.loss_partial, 0, (size_t)blocks * 4, s));
+  a.fallback_role = 1;
+  rc = run_mfma(a, D, nchw, temperature != 1.0f, false, s);
+  if (rc != VQ_OK) return rc;
+  // 5. rows that are not finite or degenerate (and every row of a flagged codebook): the exact kernel
+  a.fallback_role = 0;
+  a.loss_partial = loss_partial;
+  float* fix_loss = loss_partial ? loss_partial + blocks : nullptr;
+  return run_exact(a, D, nchw, true, fix_loss, VQ_FIX_WGS, s);
+}
+
 int vq_search_exact(const float* z, int layout, int64_t N, int D, int64_t HW, const float* E, const float* e2,
                     int K, float temperature, int64_t code_base, int64_t* idx64, int32_t* idx32, float* dmin,
                     float* q_out, float* loss_partial, void* stream) {
@@ -900,7 +1094,7 @@ int vq_gather_st(const float* z, int layout, int64_t N, int D, int64_t HW, const
   const int64_t blocks = vq_search_blocks(N);
   hipLaunchKernelGGL(vq_gather_st_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, z,
                      layout == VQ_LAYOUT_NCHW ? 1 : 0, N, D, layout == VQ_LAYOUT_NCHW ? HW : 1, E, K, idx64, q_out,
-                     loss_partial);
+                     loss_partial, (const int32_t*)nullptr);
   return vq_hip_status(hipGetLastError());
 }
 

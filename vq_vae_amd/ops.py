@@ -99,10 +99,20 @@ def prepare_codebook(E: torch.Tensor, ws: Workspace):
     return image, e2, control
 
 
+def filter_supported(K: int, D: int, temperature: float, code_base: int, want_quantized: bool) -> bool:
+    """Shapes the filtered search covers (the limits of vq_search_filtered)."""
+    return (D in (64, 128, 256) and 0 < K <= 8192 and 0.0 < temperature < float("inf")
+            and not (want_quantized and code_base != 0))
+
+
 def search(z: torch.Tensor, E: torch.Tensor, ws: Workspace, temperature: float = 1.0, code_base: int = 0,
            want_quantized: bool = True, want_dmin: bool = False, exact: bool = False, prepared=None,
-           events=None, allow_split: bool = True):
+           events=None, allow_split: bool = True, filtered: bool = False):
     """Nearest-codebook search (+ fused gather / straight-through / loss partials).
+
+    ``filtered`` selects vq_search_filtered (bf16 matrix-core filter + exact fp32 verification:
+    identical indices, several times faster on large batches) where it is supported, and the
+    plain fp32 search elsewhere.
 
     Returns dict(indices int64 [N], idx32, dmin|None, quantized|None, loss_partial|None, n_partial).
     """
@@ -117,12 +127,26 @@ def search(z: torch.Tensor, E: torch.Tensor, ws: Workspace, temperature: float =
     idx32 = ws.get("idx32", N * 4, torch.int32)
     dmin = torch.empty(N, dtype=torch.float32, device=dev) if want_dmin else None
     q = torch.empty_like(z) if want_quantized else None
-    n_partial = lib.vq_loss_partial_bytes(N) // 4
+    use_filter = (filtered and not exact and filter_supported(K, D, float(temperature), code_base, want_quantized))
+    n_partial = (lib.vq_filter_loss_partial_bytes(N) if use_filter else lib.vq_loss_partial_bytes(N)) // 4
     lp = ws.get("loss_partial", n_partial * 4, torch.float32) if want_quantized else None
     s = _stream(dev)
     if exact:
         check(lib.vq_search_exact(_ptr(z), layout, N, D, HW, _ptr(E), _ptr(e2), K, float(temperature), code_base,
                                   _ptr(idx64), _ptr(idx32), _ptr(dmin), _ptr(q), _ptr(lp), s), "vq_search_exact")
+    elif use_filter:
+        nf_rows = ws.get("nf_rows", N * 4, torch.int32)
+        fimage = ws.get("fimage", lib.vq_filter_image_bytes(K, D))
+        work = ws.get("fwork", lib.vq_filter_work_bytes(N))
+        if events is not None:
+            events[0].record(torch.cuda.current_stream(dev))
+        check(lib.vq_filter_prep(_ptr(E), _ptr(e2), K, D, _ptr(fimage), s), "vq_filter_prep")
+        check(lib.vq_search_filtered(_ptr(z), layout, N, D, HW, _ptr(E), _ptr(image), _ptr(e2), _ptr(fimage), K,
+                                     float(temperature),
+                                     code_base, _ptr(idx64), _ptr(idx32), _ptr(dmin), _ptr(q), _ptr(lp),
+                                     _ptr(nf_rows), _ptr(control), _ptr(work), s), "vq_search_filtered")
+        if events is not None:
+            events[1].record(torch.cuda.current_stream(dev))
     else:
         nf_rows = ws.get("nf_rows", N * 4, torch.int32)
         split_bytes = lib.vq_search_split_bytes(N, K) if allow_split else 0
