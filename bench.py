@@ -117,6 +117,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=4 * 1024 * 1024, help="latent vectors per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-filtered", action="store_true", help="skip the extra timing of the filtered search")
     ap.add_argument("--codebook", choices=["normal", "ref-init"], default="normal",
                     help="normal: N(0,1) rows (high utilisation, the headline case); ref-init: the reference's "
                          "U(-1/K, 1/K) initialisation, which collapses onto a few codes (skewed EMA scatter)")
@@ -159,38 +160,66 @@ def main() -> None:
 
     ev_pairs = []
 
-    def step(timed: bool):
+    def step(timed: bool, filtered: bool = False):
         ev = None
         if timed:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev_pairs.append(ev)
         return ops.quantize_step(z, E, ema_w, cs, usage, beta=BETA, decay=DECAY, epsilon=EPS, temperature=1.0,
-                                 training=True, ws=ws, stats_reduce=stats_reduce, search_events=ev)
+                                 training=True, ws=ws, stats_reduce=stats_reduce, search_events=ev, filtered=filtered)
 
-    for _ in range(args.warmup):
-        out = step(False)
+    def timed_run(filtered: bool) -> float:
+        """W untimed + K timed steps, barrier + synchronize on both sides, max over ranks (seconds)."""
+        for _ in range(args.warmup):
+            step(False, filtered)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(True, filtered)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    elapsed = timed_run(False)
+    out = step(False)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step(True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     search_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_pairs]))
     flops = 2.0 * rows * K * D                       # algorithmic: one N x K x D contraction per step
     achieved = flops / (search_ms * 1e-3) / 1e12
     # sanity of the last step's outputs (cheap; outside the timed region)
     assert out.indices.shape[0] == rows and bool(torch.isfinite(out.loss)) and bool(torch.isfinite(out.perplexity))
+
+    # the same step with the filtered search (bf16 matrix-core filter + exact fp32 verification of the
+    # surviving candidates): identical outputs, reported beside the fp32 headline, never as `value`
+    filt = None
+    if not args.no_filtered:
+        ev_fp32 = list(ev_pairs)
+        ev_pairs.clear()
+        E.copy_(E0); ema_w.zero_(); cs.zero_(); usage.zero_()
+        ref = ops.search(z, E, ws, want_quantized=False)["indices"].clone()
+        got = ops.search(z, E, ws, want_quantized=False, filtered=True)["indices"]
+        same = bool(torch.equal(ref, got))
+        del ref, got
+        f_elapsed = timed_run(True)
+        f_search_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_pairs]))
+        filt = {"value": rows * world * args.steps / f_elapsed, "unit": "vectors/s",
+                "ms_per_step": f_elapsed / args.steps * 1e3, "search_ms": f_search_ms,
+                "indices_identical_to_fp32_search": same, "rows_compared": rows,
+                "effective_tflops": 2.0 * rows * K * D / (f_search_ms * 1e-3) / 1e12,
+                "note": "opt-in search_mode='filtered': bf16 MFMA pass under a proven error bound selects the candidates, "
+                        "fp32 chain decides; outputs bit-identical to the fp32 search"}
+        ev_pairs[:] = ev_fp32
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -219,6 +248,8 @@ def main() -> None:
                          "flops_per_launch": flops},
             "perplexity": float(out.perplexity.item()),
         }
+        if filt is not None:
+            line["filtered_search"] = filt
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             line["parity"] = parity_gate(z, E0)

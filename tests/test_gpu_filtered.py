@@ -1,0 +1,138 @@
+"""Filtered search (bf16 matrix-core filter + exact fp32 verification): its outputs must equal the
+fp32 search's and the oracle's bit for bit -- indices, winning distances, quantized output."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from inputs import gauss
+from oracle import vq_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _both(z, E, dev, T=1.0):
+    from vq_vae_amd import ops
+    ws = ops.Workspace(dev)
+    zt, Et = torch.from_numpy(z).to(dev), torch.from_numpy(E).to(dev)
+    out = {}
+    for name, filt in (("fp32", False), ("filtered", True)):
+        r = ops.search(zt, Et, ws, temperature=T, want_dmin=True, filtered=filt)
+        torch.cuda.synchronize()
+        loss = r["loss_partial"][: r["n_partial"]].double().sum().item()
+        out[name] = (r["indices"].cpu().numpy(), r["dmin"].cpu().numpy(), r["quantized"].cpu().numpy(), loss,
+                     r["control"].cpu().numpy().copy())
+    return out
+
+
+def _same_bits(a, b):
+    return np.array_equal(a.view(np.int32), b.view(np.int32))
+
+
+@pytest.mark.parametrize("K,D,shape,T", [
+    (512, 64, (16, 64, 16, 16), 1.0),          # benchmark config 1
+    (1000, 64, (4, 64, 16, 16), 1.0),          # K not a multiple of the 128-code stage
+    (512, 128, (5000, 128), 1.0),              # (N, D) layout, ragged row count
+    (8192, 256, (8, 256, 32, 32), 1.0),        # benchmark config 2 shape
+    (8192, 256, (8, 256, 32, 32), 2.5),        # temperature
+    (300, 256, (1, 256, 7, 9), 0.7),
+])
+def test_filtered_equals_oracle(dev, K, D, shape, T):
+    z = gauss(400 + K + D, shape)
+    E = gauss(401 + K, (K, D))
+    o = _both(z, E, dev, T)
+    idx_o, dmin_o = vo.search(z, E, T=T)
+    for name in ("fp32", "filtered"):
+        idx, dmin, q, loss, ctl = o[name]
+        assert np.array_equal(idx, idx_o), name
+        assert _same_bits(dmin, np.asarray(dmin_o, np.float32)), name
+    assert _same_bits(o["fp32"][2], o["filtered"][2])
+    assert abs(o["fp32"][3] - o["filtered"][3]) <= 1e-6 * abs(o["fp32"][3])
+
+
+def test_filtered_close_codes_and_ties(dev):
+    """Clustered latents, duplicated codes (exact ties -> lowest index) and a codebook whose codes
+    are too close for the filter (reference-style U(-1/K, 1/K) init -> fp32 fall-back)."""
+    K, D = 2048, 64
+    E = gauss(410, (K, D))
+    rng = np.random.default_rng(5)
+    z = (E[rng.integers(0, K, 8192)] + np.float32(0.05) * gauss(411, (8192, D))).astype(np.float32)
+    Edup = E.copy(); Edup[K // 2:] = Edup[: K // 2]
+    Eref = ((np.random.default_rng(6).random((K, D), dtype=np.float32) * 2 - 1) / K).astype(np.float32)
+    for Ecase, expect_fallback in ((E, False), (Edup, None), (Eref, True)):
+        o = _both(z, Ecase, dev)
+        idx_o, dmin_o = vo.search(z, Ecase)
+        assert np.array_equal(o["filtered"][0], idx_o)
+        assert _same_bits(o["filtered"][1], np.asarray(dmin_o, np.float32))
+        assert _same_bits(o["filtered"][2], o["fp32"][2])
+        if expect_fallback is not None:
+            unsettled = int(o["filtered"][4][4])           # rows left after the first pass
+            assert (unsettled * 8 > z.shape[0]) == expect_fallback
+    assert idx_o.max() < K
+
+
+def test_filtered_nonfinite_rows(dev):
+    """NaN / inf / huge / all-zero rows leave the filtered path for the exact kernel and come out
+    exactly as from the fp32 search (torch.argmin's NaN rule included)."""
+    K, D = 512, 64
+    E = gauss(420, (K, D))
+    z = gauss(421, (8, D, 16, 16))
+    z[0, :, 0, 0] = np.nan
+    z[1, 3, 2, 2] = np.inf
+    z[2, :, 4, 4] = 0.0
+    z[3, :, 5, 5] = 1e20
+    z[4, 7, 1, 1] = -np.inf
+    o = _both(z, E, dev)
+    assert np.array_equal(o["fp32"][0], o["filtered"][0])
+    assert np.array_equal(o["fp32"][2].view(np.int32), o["filtered"][2].view(np.int32))
+    idx_o, _ = vo.search(z, E)
+    assert np.array_equal(o["filtered"][0], idx_o)
+    assert int(o["filtered"][4][0]) >= 5                   # at least those five rows took the exact kernel
+
+
+def test_filtered_module_step_matches_fp32(dev):
+    """A training step of the module in 'filtered' mode leaves exactly the state of 'fp32' mode."""
+    from vq_vae_amd import EMAVectorQuantizer
+    K, D = 1024, 64
+    E = gauss(430, (K, D)) * np.float32(0.5)
+    z = torch.from_numpy(gauss(431, (40, D, 32, 32))).to(dev)        # 40960 rows >= filtered_min_rows
+    res = {}
+    for mode in ("fp32", "filtered"):
+        m = EMAVectorQuantizer(K, D, 3.0).to(dev)
+        m.search_mode = mode
+        with torch.no_grad():
+            m.embedding.weight.copy_(torch.from_numpy(E))
+        m.train()
+        for _ in range(2):
+            q, loss, (perp, idx, _) = m(z, temperature=1.0)
+        torch.cuda.synchronize()
+        res[mode] = (q, loss, perp, idx, {k: v.clone() for k, v in m.state_dict().items()})
+    a, b = res["fp32"], res["filtered"]
+    assert torch.equal(a[3], b[3]) and torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+    assert abs(a[1].item() - b[1].item()) <= 1e-6 * abs(a[1].item())
+    for k in a[4]:
+        assert torch.equal(a[4][k], b[4][k]), k
+    with pytest.raises(ValueError):
+        m.search_mode = "bf16"
+        m(z)
+
+
+def test_filtered_unsupported_shapes_use_fp32(dev):
+    """D outside {64,128,256} or K > 8192: ops.search silently runs the fp32 search; the C entry
+    point itself reports VQ_ERR_UNSUPPORTED."""
+    from vq_vae_amd import ops, _lib
+    z = gauss(440, (300, 32)); E = gauss(441, (128, 32))
+    ws = ops.Workspace(dev)
+    r = ops.search(torch.from_numpy(z).to(dev), torch.from_numpy(E).to(dev), ws, filtered=True)
+    assert np.array_equal(r["indices"].cpu().numpy(), vo.search(z, E)[0])
+    assert not ops.filter_supported(16384, 256, 1.0, 0, True)
+    assert not ops.filter_supported(512, 64, 0.0, 0, True)
+    lib = _lib.load()
+    assert lib.vq_filter_image_bytes(16384, 256) == 256

@@ -17,13 +17,23 @@
 //      exact scalar kernel through the same list the fp32 path uses.
 //
 // Error bound.  With z = z~ + dz and e = e~ + de (bf16 round-to-nearest),
-//   z.e - z~.e~ = z~.de + dz.e, so |2 z.e - 2 z~.e~| <= 2 (||z~|| ||de|| + ||dz|| ||e||)
-// by Cauchy-Schwarz; ||dz||, ||z~|| are computed per row from the actual rounding errors and
-// max ||de||, max ||e|| per codebook.  Products of two bf16 are exact in fp32; the fp32 accumulation
-// of the matrix core and the rounding of the fp32 chain itself are covered by (D + 16) 2^-21 times
-// the sum of the magnitudes.  ||e_k||^2 enters the contraction exactly, as three bf16 terms times
-// 1.0, and c_n >= ||z||^2 + delta_n (rounded up to bf16, times 1.0) keeps every a[n,k] positive, so
-// that keys order as unsigned/positive floats.
+//   z.e - z~.e~ = z~.de + dz.e, so |2 z.e - 2 z~.e~| <= 2 (||z~|| ||de_k|| + ||dz|| ||e_k||)
+// by Cauchy-Schwarz; ||dz||, ||z~|| are computed per row and ||de_k||, ||e_k|| per code from the
+// actual rounding errors.  Products of two bf16 are exact in fp32; the fp32 accumulation of the
+// matrix core and the rounding of the fp32 chain itself are covered by (D + 16) 2^-21 times the
+// sum of the magnitudes, (||z|| + ||e_k||)^2 on either side (the chain needs (D + 2) 2^-24 of it;
+// the rest allows the matrix core 7 ulp per accumulated product).  All of it is linear in three
+// per-code numbers with per-row coefficients,
+//   delta[n,k] = const_n + c1_n ||de_k|| + c2_n ||e_k|| + c3_n ||e_k||^2,
+// so the matrix core subtracts the code-dependent part itself: three more slots of the extra
+// k-step hold (||de_k||, ||e_k||, ||e_k||^2) against (-c1_n, -c2_n, -c3_n), all rounded up in
+// magnitude to bf16, and a key is a LOWER bound L[n,k] of d + c_n - const_n.  With k^ the code of
+// the smallest key, every code that can be the fp32 argmin has
+//   L[n,k] <= L[n,k^] + 2 (delta[n,k^] - const_n) + 2 const_n        (+ the key truncation),
+// so a code pays for its own norm only and the threshold for the best code's.
+// ||e_k||^2 itself enters the contraction exactly, as three bf16 terms times 1.0, and
+// c_n >= ||z||^2 + max_k delta[n,k] (rounded up to bf16, times 1.0) keeps every key positive, so
+// that keys order as unsigned integers and as floats alike.
 #include "vq_common.h"
 
 namespace {
@@ -45,6 +55,8 @@ __device__ __forceinline__ uint32_t bf16_pair(float lo, float hi) {
   v[1] = (__bf16)hi;
   return __builtin_bit_cast(uint32_t, v);
 }
+// smallest bf16 value >= x, as a float (x >= 0, finite)
+__device__ __forceinline__ float bf16_up(float x) { return __uint_as_float((__float_as_uint(x) + 0xffffu) & 0xffff0000u); }
 __device__ __forceinline__ float bf16_lo(uint32_t p) { return __uint_as_float(p << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
 
@@ -53,12 +65,14 @@ __host__ __device__ inline int fq_tiles(int K) { return (K + 32 * FQ_STAGE_TILES
 
 // ---------------------------------------------------------------------------------------
 // bf16 codebook image: [tile][step][lane] fragments of 8 bf16.  Lane (i, g) of step s holds
-// -2 e~[32 tile + i][16 s + 8 g + 0..7]; the last step holds (e2_hi, e2_mid, e2_lo, 1, 0...) in
-// the g = 0 lanes.  hdr[0], hdr[1] = max ||e||^2, max ||e - e~||^2 (bit patterns, atomicMax).
+// -2 e~[32 tile + i][16 s + 8 g + 0..7]; the last step holds (e2_hi, e2_mid, e2_lo, 1, ||de||, ||e||,
+// ||e||^2, 0) in the g = 0 lanes, the last three rounded up to bf16 and also stored as floats in
+// aux[code] for the verification.  hdr[0..2] = max of those three (bit patterns, atomicMax).
 // ---------------------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(64) void vqf_prep_kernel(const float* __restrict__ E, const float* __restrict__ e2, int K,
-                                                      u32x4* __restrict__ image, uint32_t* __restrict__ hdr) {
+                                                      u32x4* __restrict__ image, uint32_t* __restrict__ hdr,
+                                                      f32x4* __restrict__ aux) {
   constexpr int FS = D / 16 + 1;
   const int lane = threadIdx.x, i = lane & 31, g = lane >> 5;
   const int tile = blockIdx.x, code = tile * 32 + i;
@@ -86,10 +100,6 @@ __global__ __launch_bounds__(64) void vqf_prep_kernel(const float* __restrict__ 
   }
   en += __shfl_xor(en, 32);
   de += __shfl_xor(de, 32);
-  if (g == 0 && real) {
-    atomicMax(&hdr[0], __float_as_uint(en));
-    atomicMax(&hdr[1], __float_as_uint(de));
-  }
   u32x4 o = u32x4{0, 0, 0, 0};
   if (g == 0) {
     float n2 = real ? e2[code] : FQ_PAD_NORM;
@@ -98,8 +108,20 @@ __global__ __launch_bounds__(64) void vqf_prep_kernel(const float* __restrict__ 
     const float r1 = n2 - hi;
     const float mid = __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
     const float lo = r1 - mid;
+    // per-code terms of the error bound, rounded up to bf16 (padding codes: 0, they never win)
+    const float pde = real ? bf16_up(__builtin_sqrtf(de) * 1.0001f) : 0.0f;
+    const float pen = real ? bf16_up(__builtin_sqrtf(en) * 1.0001f) : 0.0f;
+    const float pe2 = real ? bf16_up(en * 1.0001f) : 0.0f;
     o[0] = bf16_pair(hi, mid);
     o[1] = bf16_pair(lo, 1.0f);
+    o[2] = bf16_pair(pde, pen);
+    o[3] = bf16_pair(pe2, 0.0f);
+    aux[code] = f32x4{pde, pen, pe2, 0.0f};
+    if (real) {
+      atomicMax(&hdr[0], __float_as_uint(pde));
+      atomicMax(&hdr[1], __float_as_uint(pen));
+      atomicMax(&hdr[2], __float_as_uint(pe2));
+    }
   }
   dst[(D / 16) * 64] = o;
 }
@@ -112,9 +134,9 @@ struct FilterArgs {
   int64_t HW;
   int nstages;
   u32x4* cand;     // [rows][2][R/4] : the R smallest keys of each lane half (unused slots +inf)
-  float* band;     // [rows]
+  f32x4* rowaux;   // [rows] : const_n, c1_n, c2_n, c3_n of the error bound (c's as rounded to bf16)
   int32_t* control;
-  // list mode: the launch covers rows row_list[0 .. control[count_word]); cand / band are indexed
+  // list mode: the launch covers rows row_list[0 .. control[count_word]); cand / rowaux are indexed
   // by the position in the list
   const int32_t* row_list;
   int count_word;
@@ -177,11 +199,10 @@ __global__ __launch_bounds__(512, 2) void vqf_filter_kernel(FilterArgs a) {
 
   fq_stage_copy<D>(a.image, 0, flds, wave, lane);
 
-  const float emax = __builtin_sqrtf(__uint_as_float(a.hdr[0])) * 1.0001f;
-  const float demax = __builtin_sqrtf(__uint_as_float(a.hdr[1])) * 1.0001f;
+  const float demax = __uint_as_float(a.hdr[0]), emax = __uint_as_float(a.hdr[1]), e2max = __uint_as_float(a.hdr[2]);
 
   u32x4 zb[2][FS];
-  float band[2];
+  f32x4 rowaux[2];
   uint32_t zmax_bits = 0;
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) {
@@ -222,19 +243,23 @@ __global__ __launch_bounds__(512, 2) void vqf_filter_kernel(FilterArgs a) {
     zmax_bits = am > zmax_bits ? am : zmax_bits;
     zt2 += __shfl_xor(zt2, 32);
     dz2 += __shfl_xor(dz2, 32);
-    // rigorous half-width of |a - (d + c)| for this row (see the file comment)
+    // coefficients of the error bound for this row (see the file comment)
     const float nz = __builtin_sqrtf(zt2) * 1.0001f, ndz = __builtin_sqrtf(dz2) * 1.0001f;
-    const float zc = nz + ndz;                                   // >= ||z||
-    const float delta0 = 2.0f * (nz * demax + ndz * emax) * 1.0001f + 1.0e-30f + nz * 1.0e-35f;
-    const float mag = 2.0f * (zc + emax) * (zc + emax) + delta0;  // >= sum of magnitudes in either evaluation
-    const float delta = delta0 + mag * ((float)(D + 16) * 4.76837158203125e-07f) * 1.01f;
-    band[ct] = 2.0f * delta * 1.0001f;
-    const float cshift = zc * zc * 1.0001f + delta;
-    const float cup = __uint_as_float((__float_as_uint(cshift) + 0xffffu) & 0xffff0000u);  // bf16, rounded up
+    const float zc = nz + ndz;                                              // >= ||z||
+    const float gam = (float)(D + 16) * 4.76837158203125e-07f * 1.01f;      // (D + 16) 2^-21
+    const float c1 = bf16_up(2.0f * nz * 1.0001f);                          // times ||de_k||
+    const float c2 = bf16_up((2.0f * ndz + 4.0f * gam * zc) * 1.0001f);     // times ||e_k||
+    const float c3 = bf16_up(2.0f * gam);                                   // times ||e_k||^2
+    const float wmax = (c1 * demax + c2 * emax + c3 * e2max) * 1.0001f;     // largest code-dependent part
+    const float cst = (gam * (2.0f * zc * zc * 1.0001f + 4.0f * wmax) + 1.0e-30f + nz * 1.0e-35f) * 1.001f;
+    rowaux[ct] = f32x4{cst, c1, c2, c3};
+    const float cup = bf16_up(zc * zc * 1.0001f + (2.0f * wmax + cst) * 1.0001f);  // keeps every key positive
     u32x4 extra = u32x4{0, 0, 0, 0};
     if (g == 0) {
       extra[0] = bf16_pair(1.0f, 1.0f);
       extra[1] = bf16_pair(1.0f, cup);
+      extra[2] = bf16_pair(-c1, -c2);
+      extra[3] = bf16_pair(-c3, 0.0f);
     }
     zb[ct][ZS] = extra;
   }
@@ -292,13 +317,13 @@ __global__ __launch_bounds__(512, 2) void vqf_filter_kernel(FilterArgs a) {
 
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) {
-    const int64_t pos = row0 + ct * 32 + j;   // cand / band are indexed by position (= row unless listed)
+    const int64_t pos = row0 + ct * 32 + j;   // cand / rowaux are indexed by position (= row unless listed)
     if (pos < nrows) {
 #pragma unroll
       for (int q = 0; q < R / 4; ++q)
         a.cand[(pos * 2 + g) * (R / 4) + q] = u32x4{__float_as_uint(m[ct][4 * q]), __float_as_uint(m[ct][4 * q + 1]),
                                                    __float_as_uint(m[ct][4 * q + 2]), __float_as_uint(m[ct][4 * q + 3])};
-      if (g == 0) a.band[pos] = band[ct];
+      if (g == 0) a.rowaux[pos] = rowaux[ct];
     }
   }
 }
@@ -308,7 +333,8 @@ struct VerifyArgs {
   const float* E;
   const float* e2;
   const u32x4* cand;
-  const float* band;
+  const f32x4* rowaux;
+  const f32x4* aux;      // per-code (||de||, ||e||, ||e||^2) as the filter used them
   int64_t N;
   int64_t HW;
   int K;
@@ -353,11 +379,17 @@ __global__ __launch_bounds__(256) void vqf_verify_kernel(VerifyArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) kh[g][4 * q + i] = v[i];
     }
-  const float band = a.band[pos];
+  const f32x4 ra = a.rowaux[pos];
   const float v0 = __uint_as_float(kh[0][0] & FQ_KEY_MASK), v1 = __uint_as_float(kh[1][0] & FQ_KEY_MASK);
   const int g0 = v1 < v0 ? 1 : 0;                 // half that holds the smallest key
   const float mn = g0 ? v1 : v0;
-  const float thr = mn * 1.0009765625f + band;    // key truncation: value in (a (1 - 2^-11), a]
+  // threshold: twice the best code's own error terms plus twice the row constant (file comment);
+  // key truncation: value in (L (1 - 2^-11), L]
+  int kbest = fq_decode(g0 ? kh[1][0] : kh[0][0], g0);
+  if (kbest >= a.K) kbest = 0;                    // garbage keys (flagged codebook): the row goes to the exact kernel
+  const f32x4 ca = a.aux[kbest];
+  const float wbest = (ra[1] * ca[0] + ra[2] * ca[1] + ra[3] * ca[2]) * 1.0001f;
+  const float thr = mn * 1.0009765625f + 2.0f * (wbest + ra[0]) * 1.0001f;
   if (!(thr < __builtin_inff()) || !(mn >= 0.0f)) exact_row = true;  // also catches NaN
   int code[SL];
   bool ok[SL];
@@ -491,7 +523,7 @@ extern "C" {
 
 size_t vq_filter_image_bytes(int K, int D) {
   if (!vq_filter_supported(K, D)) return 256;
-  return (size_t)fq_tiles(K) * fq_steps(D) * 1024 + 256;
+  return (size_t)fq_tiles(K) * fq_steps(D) * 1024 + 256 + (size_t)fq_tiles(K) * 32 * 16;  // image, header, per-code terms
 }
 
 
@@ -502,17 +534,18 @@ int vq_filter_prep(const float* E, const float* e2, int K, int D, void* fimage, 
   const int tiles = fq_tiles(K);
   u32x4* image = static_cast<u32x4*>(fimage);
   uint32_t* hdr = reinterpret_cast<uint32_t*>(static_cast<char*>(fimage) + (size_t)tiles * fq_steps(D) * 1024);
+  f32x4* aux = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(hdr) + 256);
   VQ_CHECK_HIP(hipMemsetAsync(hdr, 0, 256, s));
   switch (D) {
-    case 64: hipLaunchKernelGGL(vqf_prep_kernel<64>, dim3(tiles), dim3(64), 0, s, E, e2, K, image, hdr); break;
-    case 128: hipLaunchKernelGGL(vqf_prep_kernel<128>, dim3(tiles), dim3(64), 0, s, E, e2, K, image, hdr); break;
-    default: hipLaunchKernelGGL(vqf_prep_kernel<256>, dim3(tiles), dim3(64), 0, s, E, e2, K, image, hdr); break;
+    case 64: hipLaunchKernelGGL(vqf_prep_kernel<64>, dim3(tiles), dim3(64), 0, s, E, e2, K, image, hdr, aux); break;
+    case 128: hipLaunchKernelGGL(vqf_prep_kernel<128>, dim3(tiles), dim3(64), 0, s, E, e2, K, image, hdr, aux); break;
+    default: hipLaunchKernelGGL(vqf_prep_kernel<256>, dim3(tiles), dim3(64), 0, s, E, e2, K, image, hdr, aux); break;
   }
   return vq_hip_status(hipGetLastError());
 }
 
-// Work buffer: [keys of pass 1: N x 32][band: N x 4][list A: N x 4][keys of pass 2: N x 64][band: N x 4][list B: N x 4]
-size_t vq_filter_work_bytes(int64_t N) { return N > 0 ? (size_t)N * 112 : 256; }
+// Work buffer: [keys of pass 1: N x 32][row terms: N x 16][list A: N x 4][keys of pass 2: N x 64][row terms: N x 16][list B: N x 4]
+size_t vq_filter_work_bytes(int64_t N) { return N > 0 ? (size_t)N * 136 : 256; }
 
 // Internal (benchmarks): the first-pass filter kernel alone.
 int vq_filter_only_launch(const float* z, int nchw, int64_t N, int D, int64_t HW, const void* fimage, int K,
@@ -523,7 +556,7 @@ int vq_filter_only_launch(const float* z, int nchw, int64_t N, int D, int64_t HW
   f.hdr = reinterpret_cast<const uint32_t*>(static_cast<const char*>(fimage) + (size_t)tiles * fq_steps(D) * 1024);
   f.N = N; f.HW = nchw ? HW : 1; f.nstages = tiles / FQ_STAGE_TILES;
   f.cand = static_cast<u32x4*>(work);
-  f.band = reinterpret_cast<float*>(static_cast<char*>(work) + (size_t)N * 32);
+  f.rowaux = reinterpret_cast<f32x4*>(static_cast<char*>(work) + (size_t)N * 32);
   f.control = control;
   return dispatch_filter<4>(f, D, nchw != 0, (hipStream_t)stream);
 }
@@ -538,31 +571,32 @@ int vq_filter_verify_launch(const float* z, int nchw, int64_t N, int D, int64_t 
   hipStream_t s = (hipStream_t)stream;
   const int tiles = fq_tiles(K);
   char* w = static_cast<char*>(work);
-  int32_t* listA = reinterpret_cast<int32_t*>(w + (size_t)N * 36);
-  int32_t* listB = reinterpret_cast<int32_t*>(w + (size_t)N * 108);
+  int32_t* listA = reinterpret_cast<int32_t*>(w + (size_t)N * 48);
+  int32_t* listB = reinterpret_cast<int32_t*>(w + (size_t)N * 132);
   *hard_rows_out = listB;
   FilterArgs f{};
   f.z = z; f.image = static_cast<const u32x4*>(fimage);
   f.hdr = reinterpret_cast<const uint32_t*>(static_cast<const char*>(fimage) + (size_t)tiles * fq_steps(D) * 1024);
   f.N = N; f.HW = nchw ? HW : 1; f.nstages = tiles / FQ_STAGE_TILES;
   f.cand = reinterpret_cast<u32x4*>(w);
-  f.band = reinterpret_cast<float*>(w + (size_t)N * 32);
+  f.rowaux = reinterpret_cast<f32x4*>(w + (size_t)N * 32);
   f.control = control;
   int rc = dispatch_filter<4>(f, D, nchw != 0, s);
   if (rc != VQ_OK) return rc;
   VerifyArgs v{};
-  v.z = z; v.E = E; v.e2 = e2; v.cand = f.cand; v.band = f.band; v.N = N; v.HW = f.HW; v.K = K; v.D = D; v.T = T;
+  v.z = z; v.E = E; v.e2 = e2; v.cand = f.cand; v.rowaux = f.rowaux; v.N = N; v.HW = f.HW; v.K = K; v.D = D; v.T = T;
   v.code_base = code_base; v.idx64 = idx64; v.idx32 = idx32; v.dmin = dmin; v.nf_rows = nf_rows; v.control = control;
+  v.aux = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(f.hdr) + 256);
   v.ovf_rows = listA; v.ovf_word = VQ_CTL_OVF_COUNT;
   rc = launch_verify<4>(v, nchw != 0, s);
   if (rc != VQ_OK) return rc;
   // second level over list A: 8 keys per lane
-  f.cand = reinterpret_cast<u32x4*>(w + (size_t)N * 40);
-  f.band = reinterpret_cast<float*>(w + (size_t)N * 104);
+  f.cand = reinterpret_cast<u32x4*>(w + (size_t)N * 52);
+  f.rowaux = reinterpret_cast<f32x4*>(w + (size_t)N * 116);
   f.row_list = listA; f.count_word = VQ_CTL_OVF_COUNT;
   rc = dispatch_filter<8>(f, D, nchw != 0, s);
   if (rc != VQ_OK) return rc;
-  v.cand = f.cand; v.band = f.band; v.row_list = listA; v.count_word = VQ_CTL_OVF_COUNT;
+  v.cand = f.cand; v.rowaux = f.rowaux; v.row_list = listA; v.count_word = VQ_CTL_OVF_COUNT;
   v.ovf_rows = listB; v.ovf_word = VQ_CTL_OVF2_COUNT;
   return launch_verify<8>(v, nchw != 0, s);
 }

@@ -268,7 +268,7 @@ def gather_st(z: torch.Tensor, E: torch.Tensor, idx64: torch.Tensor, ws: Workspa
 
 def quantize_step(z: torch.Tensor, E: torch.Tensor, ema_w, cluster_size, usage, *, beta: float, decay: float,
                   epsilon: float, temperature: float, training: bool, ws: Workspace, want_dmin: bool = False,
-                  stats_reduce=None, search_events=None) -> StepResult:
+                  stats_reduce=None, search_events=None, filtered: bool = False) -> StepResult:
     """One full forward of the quantizer: search, gather, loss, histogram, perplexity and, in
     training mode, the EMA update of (usage, cluster_size, ema_w, E) in place.
 
@@ -278,7 +278,8 @@ def quantize_step(z: torch.Tensor, E: torch.Tensor, ema_w, cluster_size, usage, 
     local-batch mean, as it would under DistributedDataParallel.
     """
     K, D = E.shape
-    r = search(z, E, ws, temperature=temperature, want_quantized=True, want_dmin=want_dmin, events=search_events)
+    r = search(z, E, ws, temperature=temperature, want_quantized=True, want_dmin=want_dmin, events=search_events,
+               filtered=filtered)
     N = r["N"]
     counts = ws.get("counts", K * 4, torch.int32)
     histogram(r["idx32"][:N], K, ws, out=counts)
