@@ -10,7 +10,8 @@ import os
 from ctypes import c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libvqhip.so")
+#: the library built in-tree; VQ_VAE_AMD_LIB selects another build of the same ABI (kernel experiments)
+LIB_PATH = os.environ.get("VQ_VAE_AMD_LIB") or os.path.join(_PKG, "libvqhip.so")
 
 LAYOUT_ND, LAYOUT_NCHW = 0, 1
 

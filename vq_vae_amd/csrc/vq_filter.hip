@@ -146,9 +146,12 @@ template <int D>
 __device__ __forceinline__ void fq_stage_copy(const u32x4* image, int stage, char* lds_buf, int wave, int lane) {
   constexpr int PIECES = FQ_STAGE_TILES * (D / 16 + 1);
   const char* src = reinterpret_cast<const char*>(image) + (size_t)stage * PIECES * 1024 + lane * 16;
+  // waves 0-3 issue the DMA (one per SIMD); their partners 4-7 start the stage's MFMAs at once
+  constexpr int NL = 4;
+  if (wave >= NL) return;
 #pragma unroll
-  for (int i = 0; i < (PIECES + 7) / 8; ++i) {
-    const int p = i * 8 + wave;
+  for (int i = 0; i < (PIECES + NL - 1) / NL; ++i) {
+    const int p = i * NL + wave;
     if (p < PIECES) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)p * 1024),
                                        (__attribute__((address_space(3))) void*)(lds_buf + p * 1024), 16, 0, 0);
@@ -428,10 +431,17 @@ __global__ __launch_bounds__(256) void vqf_verify_kernel(VerifyArgs a) {
   // 16 channels per step: a lane's four 16-byte reads of a code row are issued back to back, so
   // the 64-byte sector fetched by the first serves the other three (rows of different lanes share
   // nothing, so a sector used once would cost four times the traffic).
-  for (int c16 = 0; c16 < a.D / 16; ++c16) {
+  const int n16 = a.D / 16;
+  float zn[16];  // the next step's latent values are in flight while this step computes
+#pragma unroll
+  for (int i = 0; i < 16; ++i) zn[i] = zrow[(int64_t)i * zst];
+  for (int c16 = 0; c16 < n16; ++c16) {
     float zv[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) zv[i] = zrow[(int64_t)(16 * c16 + i) * zst];
+    for (int i = 0; i < 16; ++i) zv[i] = zn[i];
+    const int cn = c16 + 1 < n16 ? c16 + 1 : c16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) zn[i] = zrow[(int64_t)(16 * cn + i) * zst];
 #pragma unroll
     for (int i = 0; i < 16; i += 2) {
       pe = __builtin_fmaf(zv[i], zv[i], pe);
