@@ -136,3 +136,21 @@ def test_filtered_unsupported_shapes_use_fp32(dev):
     assert not ops.filter_supported(512, 64, 0.0, 0, True)
     lib = _lib.load()
     assert lib.vq_filter_image_bytes(16384, 256) == 256
+
+
+def test_filtered_shard_search_with_code_base(dev):
+    """A codebook-row shard searched with code_base (no quantized output): winners, distances and the
+    packed (distance, index) keys of the filtered search equal the fp32 search's."""
+    from vq_vae_amd import ops
+    K, D = 2048, 64
+    E = gauss(450, (K, D)); z = gauss(451, (40, D, 32, 32))
+    zt = torch.from_numpy(z).to(dev)
+    ws = ops.Workspace(dev)
+    for lo in (0, 1024):
+        Es = torch.from_numpy(E[lo:lo + 1024].copy()).to(dev)
+        a = ops.search(zt, Es, ws, code_base=lo, want_quantized=False, want_dmin=True)
+        pa = ops.pack_dist_index(a["dmin"], a["indices"]).clone()
+        b = ops.search(zt, Es, ws, code_base=lo, want_quantized=False, want_dmin=True, filtered=True)
+        pb = ops.pack_dist_index(b["dmin"], b["indices"])
+        assert torch.equal(pa, pb)
+        assert int(b["indices"].min()) >= lo and int(b["indices"].max()) < lo + 1024

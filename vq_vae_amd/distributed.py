@@ -68,7 +68,7 @@ def merge_packed_winners(packed_i64: torch.Tensor, group: Optional[dist.ProcessG
 def sharded_quantize_step(z: torch.Tensor, E_shard: torch.Tensor, ema_w_shard, cluster_size_shard, usage_shard, *,
                           K_total: int, code_base: int, beta: float, decay: float, epsilon: float,
                           temperature: float, training: bool, ws, group: Optional[dist.ProcessGroup] = None,
-                          merge=None, gather_codebook=None, sum_scalar=None):
+                          merge=None, gather_codebook=None, sum_scalar=None, filtered: bool = False):
     """Forward of a quantizer whose codebook rows are sharded over the ranks of ``group``
     (large codebooks, e.g. K = 65536 as 8 x 8192 rows); every rank sees the same rows ``z``.
 
@@ -76,14 +76,15 @@ def sharded_quantize_step(z: torch.Tensor, E_shard: torch.Tensor, ema_w_shard, c
     bytes; (2) an all-gather of the codebook shards for the gather of the quantized output,
     K*D*4 bytes; (3) one scalar SUM for the Laplace normaliser n = sum(cluster_size).  Each rank
     then updates only its own rows.  ``merge`` / ``gather_codebook`` / ``sum_scalar`` default to
-    the torch.distributed collectives and can be replaced (single-process tests).
+    the torch.distributed collectives and can be replaced (single-process tests).  ``filtered``
+    runs each shard's search through the filtered kernels (same winners and distances).
     """
     from . import ops
     from ._lib import check, load
     lib = load()
     K_loc, D = E_shard.shape
     r = ops.search(z, E_shard, ws, temperature=temperature, code_base=code_base, want_quantized=False,
-                   want_dmin=True)
+                   want_dmin=True, filtered=filtered)
     packed = ops.pack_dist_index(r["dmin"], r["indices"])
     packed = merge(packed) if merge is not None else merge_packed_winners(packed, group)
     _, idx64, idx32 = ops.unpack_dist_index(packed, ws, want_dmin=False)
