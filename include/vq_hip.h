@@ -192,6 +192,23 @@ int vq_ema_codebook_update(const float* slabs, int nslab, int K, int D, float de
 int vq_backward(const float* grad_q, const float* grad_loss, const float* z, const float* q_st, int64_t numel,
                 float coef, float* grad_z, void* stream);
 
+/*
+ * Re-seed codes in place (maintenance).  ref: the per-code loops of
+ * vqvae/ema_vector_quantizer.py:185-196 (reset_dead_codes: noise 0.2, scale 0.1), :262-274
+ * (reset_low_usage_codes: noise 0.4, scale 0.2) and the new rows of :131-148 (expand_codebook:
+ * noise 0.2, scale 0).  For every i < n_targets, with k = targets[i] and a donor d drawn
+ * uniformly from donors[0 .. n_donors):
+ *   E[k] = E[d] + noise * N(0, 1);  ema_w[k] = scale * ema_w[d];
+ *   cluster_size[k] = scale * cluster_size[d];  usage[k] = 0.
+ * All donors are read before any target is written (`stage`: vq_reseed_stage_bytes(n_targets, D)
+ * bytes).  Random numbers come from Philox4x32-10 keyed by `seed`: the draws follow the
+ * reference's distributions, not torch's generator sequence.
+ */
+size_t vq_reseed_stage_bytes(int n_targets, int D);
+int vq_reseed_codes(float* E, float* ema_w, float* cluster_size, float* usage, int K, int D, const int64_t* targets,
+                    int n_targets, const int64_t* donors, int n_donors, float noise, float scale, uint64_t seed,
+                    float* stage, void* stream);
+
 /* One-hot matrix enc[N][K] (fp32).  ref: vqvae/ema_vector_quantizer.py:54-55. */
 int vq_onehot(const int64_t* idx64, int64_t N, int K, float* enc, void* stream);
 

@@ -179,3 +179,46 @@ def test_maintenance_methods(dev):
     assert m.embedding.weight.is_cuda and m.ema_w.shape == (K + 64, D)
     q, loss, (perp, idx, enc) = m(torch.from_numpy(gauss(30, (2, D, 8, 8))).to(dev))   # still runs after expansion
     assert enc.shape[1] == K + 64 and int(idx.max()) < K + 64
+
+
+def test_reseed_kernel_semantics(dev):
+    """vq_reseed_codes through the C ABI: every target becomes one of the donors plus N(0, noise^2),
+    its EMA statistics the donor's times `scale`, usage zero; donors are read before targets are
+    written; other rows untouched; the same seed reproduces the result, another seed does not.
+    Random-number policy: the reference's distributions (uniform donor, normal noise), not its
+    generator sequence -- checked statistically."""
+    from scipy import stats as sps
+    from vq_vae_amd import ops
+    K, D = 512, 256
+    E0 = torch.from_numpy(gauss(50, (K, D))).to(dev)
+    w0 = torch.from_numpy(gauss(51, (K, D))).to(dev)
+    cs0 = torch.rand(K, device=dev) + 1.0
+    targets = torch.arange(100, 400, device=dev)
+    donors = torch.tensor([5, 6, 7, 150, 420], device=dev)              # 150 is itself a target
+    ws = ops.Workspace(dev)
+
+    def run(seed):
+        E, w, cs, us = E0.clone(), w0.clone(), cs0.clone(), torch.ones(K, device=dev)
+        ops.reseed_codes(E, w, cs, us, targets, donors, 0.25, 0.1, ws, seed=seed)
+        torch.cuda.synchronize()
+        return E, w, cs, us
+
+    E, w, cs, us = run(1234)
+    keep = torch.ones(K, dtype=torch.bool, device=dev); keep[targets] = False
+    assert torch.equal(E[keep], E0[keep]) and torch.equal(w[keep], w0[keep]) and torch.equal(cs[keep], cs0[keep])
+    assert float(us[targets].abs().sum()) == 0 and float(us[keep].sum()) == int(keep.sum())
+    # identify each target's donor from the EMA statistics (exact multiples of the donor's OLD values)
+    ratio = cs[targets][:, None] / (cs0[donors][None, :] * np.float32(0.1))
+    pick = (ratio - 1).abs().argmin(1)
+    assert torch.equal(cs[targets], cs0[donors][pick] * np.float32(0.1))
+    assert torch.equal(w[targets], w0[donors][pick] * np.float32(0.1))
+    counts = torch.bincount(pick, minlength=len(donors)).cpu().numpy()
+    assert counts.min() > 0 and sps.chisquare(counts).pvalue > 1e-4      # uniform over the donors
+    noise = ((E[targets] - E0[donors][pick]) / 0.25).cpu().numpy().ravel()   # 76800 samples
+    assert abs(noise.mean()) < 0.02 and abs(noise.std() - 1) < 0.02
+    assert sps.kstest(noise, "norm").pvalue > 1e-4
+    assert abs(sps.skew(noise)) < 0.05 and abs(sps.kurtosis(noise)) < 0.1
+    E2, *_ = run(1234)
+    assert torch.equal(E, E2)
+    E3, *_ = run(1235)
+    assert not torch.equal(E, E3)

@@ -347,6 +347,87 @@ __global__ __launch_bounds__(256) void vq_onehot_kernel(const int64_t* __restric
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Re-seeding of codes (maintenance).  Replaces the per-code Python loops of
+// vqvae/ema_vector_quantizer.py:185-196, :262-274 and the row initialisation of :131-148: a
+// target code becomes a uniformly drawn donor code plus N(0, noise^2), its EMA statistics the
+// donor's times `scale`, its usage count zero.  Random numbers: Philox4x32-10, counter =
+// (target position, channel group), key = seed -- the same seed gives the same result on any
+// launch geometry.  Two kernels (stage, commit) so that a donor that is itself a target is read
+// before anything is written.
+// ---------------------------------------------------------------------------------------
+struct Philox4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                                 uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return Philox4{c0, c1, c2, c3};
+}
+
+// two uniform 32-bit words -> two independent N(0, 1) values (Box-Muller; u1 in (0, 1])
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
+  const float u1 = ((float)(a >> 8) + 1.0f) * 5.9604644775390625e-08f;   // (k + 1) / 2^24
+  const float u2 = (float)(b >> 8) * 5.9604644775390625e-08f;            // k / 2^24
+  const float r = __builtin_sqrtf(-2.0f * logf(u1));
+  float sn, cs;
+  sincosf(6.283185307179586f * u2, &sn, &cs);
+  n0 = r * cs;
+  n1 = r * sn;
+}
+
+__global__ __launch_bounds__(256) void vq_reseed_stage_kernel(const float* __restrict__ E, const float* __restrict__ ema_w,
+                                                              const float* __restrict__ cs, int D,
+                                                              const int64_t* __restrict__ donors, int n_donors,
+                                                              float noise, float scale, uint32_t seed_lo, uint32_t seed_hi,
+                                                              float* __restrict__ stage) {
+  // stage row layout: [D new code][D new ema_w][1 new cluster size]
+  const int t = blockIdx.x;
+  const Philox4 pick = philox4x32_10((uint32_t)t, 0xffffffffu, 0u, 0u, seed_lo, seed_hi);
+  const int64_t donor = donors[(int)(((uint64_t)pick.x * (uint64_t)n_donors) >> 32)];
+  float* out = stage + (size_t)t * (2 * D + 1);
+  for (int c4 = threadIdx.x; c4 < (D + 3) / 4; c4 += 256) {
+    const Philox4 r = philox4x32_10((uint32_t)t, (uint32_t)c4, 0u, 0u, seed_lo, seed_hi);
+    float nz[4];
+    box_muller(r.x, r.y, nz[0], nz[1]);
+    box_muller(r.z, r.w, nz[2], nz[3]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = 4 * c4 + i;
+      if (c < D) {
+        out[c] = E[donor * D + c] + nz[i] * noise;
+        out[D + c] = ema_w[donor * D + c] * scale;
+      }
+    }
+  }
+  if (threadIdx.x == 0) out[2 * D] = cs[donor] * scale;
+}
+
+__global__ __launch_bounds__(256) void vq_reseed_commit_kernel(const float* __restrict__ stage, int D,
+                                                               const int64_t* __restrict__ targets, float* __restrict__ E,
+                                                               float* __restrict__ ema_w, float* __restrict__ cs,
+                                                               float* __restrict__ usage) {
+  const int t = blockIdx.x;
+  const int64_t k = targets[t];
+  const float* in = stage + (size_t)t * (2 * D + 1);
+  for (int c = threadIdx.x; c < D; c += 256) {
+    E[k * D + c] = in[c];
+    ema_w[k * D + c] = in[D + c];
+  }
+  if (threadIdx.x == 0) {
+    cs[k] = in[2 * D];
+    usage[k] = 0.0f;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -480,6 +561,24 @@ int vq_onehot(const int64_t* idx64, int64_t N, int K, float* enc, void* stream) 
   if (blocks > 8192) blocks = 8192;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(vq_onehot_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, idx64, N, K, enc);
+  return vq_hip_status(hipGetLastError());
+}
+
+size_t vq_reseed_stage_bytes(int n_targets, int D) {
+  return n_targets > 0 && D > 0 ? (size_t)n_targets * (2 * (size_t)D + 1) * 4 : 256;
+}
+
+int vq_reseed_codes(float* E, float* ema_w, float* cluster_size, float* usage, int K, int D, const int64_t* targets,
+                    int n_targets, const int64_t* donors, int n_donors, float noise, float scale, uint64_t seed,
+                    float* stage, void* stream) {
+  if (!E || !ema_w || !cluster_size || !usage || !targets || !donors || !stage) return VQ_ERR_INVALID_ARG;
+  if (K <= 0 || D <= 0 || n_targets < 0 || n_donors <= 0) return VQ_ERR_INVALID_ARG;
+  if (n_targets == 0) return VQ_OK;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(vq_reseed_stage_kernel, dim3(n_targets), dim3(256), 0, s, E, ema_w, cluster_size, D, donors,
+                     n_donors, noise, scale, (uint32_t)seed, (uint32_t)(seed >> 32), stage);
+  hipLaunchKernelGGL(vq_reseed_commit_kernel, dim3(n_targets), dim3(256), 0, s, stage, D, targets, E, ema_w,
+                     cluster_size, usage);
   return vq_hip_status(hipGetLastError());
 }
 

@@ -228,27 +228,32 @@ class EMAVectorQuantizer(nn.Module):
         if old_size > 0:
             usage = self.usage_count[:old_size].to(device)
             _, top = torch.topk(usage, min(100, old_size))
-            pick = top[torch.randint(0, len(top), (new_size - old_size,), device=device)]
-            fresh = old_weight[pick].clone()
-            fresh += torch.randn_like(fresh) * 0.2
-            new_embedding.weight.data[old_size:] = fresh
         self.embedding = new_embedding
         for name in ("ema_cluster_size", "ema_w", "usage_count"):
             old = getattr(self, name)
             new = torch.zeros((new_size,) + tuple(old.shape[1:]), device=old.device)
             new[:old_size] = old
             self.register_buffer(name, new)
+        if old_size > 0:
+            # new rows: a random top-usage code + N(0, 0.2^2); their EMA statistics stay zero (scale 0)
+            self._reseed(torch.arange(old_size, new_size, device=device), top, 0.2, 0.0)
         print(f"Codebook expanded from {old_size} to {new_size}")
         return True
 
     def _reseed(self, targets: torch.Tensor, donors: torch.Tensor, noise: float, scale: float) -> None:
-        device = self.embedding.weight.device
-        pick = donors[torch.randint(0, len(donors), (len(targets),), device=device)]
+        """One kernel pair for all targets (Philox noise, seeded from torch's CPU generator)."""
         w = self.embedding.weight.data
-        w[targets] = w[pick] + torch.randn(len(targets), self.embedding_dim, device=device) * noise
-        self.ema_cluster_size[targets] = self.ema_cluster_size[pick] * scale
-        self.ema_w[targets] = self.ema_w[pick] * scale
-        self.usage_count[targets] = 0
+        if not w.is_cuda:
+            # state still on the host (module built or loaded before .to(device)): K-sized tensor ops
+            pick = donors[torch.randint(0, len(donors), (len(targets),))]
+            w[targets] = w[pick] + torch.randn(len(targets), self.embedding_dim) * noise
+            self.ema_cluster_size[targets] = self.ema_cluster_size[pick] * scale
+            self.ema_w[targets] = self.ema_w[pick] * scale
+            self.usage_count[targets] = 0
+            return
+        self._follow(w.device)
+        ops.reseed_codes(w, self.ema_w, self.ema_cluster_size, self.usage_count, targets, donors, noise, scale,
+                         self._workspace(w.device))
 
     def reset_dead_codes(self, threshold=2, current_epoch=None):
         """Re-seed codes whose EMA cluster size is below ``threshold`` (reference :165-203)."""

@@ -240,6 +240,24 @@ def backward(grad_q, grad_loss, z, q_st, coef: float) -> torch.Tensor:
     return grad_z
 
 
+def reseed_codes(E, ema_w, cluster_size, usage, targets: torch.Tensor, donors: torch.Tensor, noise: float,
+                 scale: float, ws: Workspace, seed: Optional[int] = None) -> None:
+    """vq_reseed_codes: targets become a random donor + N(0, noise^2); EMA statistics scaled.
+    The seed comes from torch's CPU generator unless given, so torch.manual_seed governs it."""
+    lib = _lib.load()
+    K, D = E.shape
+    if targets.numel() == 0:
+        return
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    targets = targets.to(device=E.device, dtype=torch.int64).contiguous()
+    donors = donors.to(device=E.device, dtype=torch.int64).contiguous()
+    stage = ws.get("reseed", lib.vq_reseed_stage_bytes(targets.numel(), D), torch.float32)
+    check(lib.vq_reseed_codes(_ptr(E), _ptr(ema_w), _ptr(cluster_size), _ptr(usage), K, D, _ptr(targets),
+                              targets.numel(), _ptr(donors), donors.numel(), float(noise), float(scale), seed,
+                              _ptr(stage), _stream(E.device)), "vq_reseed_codes")
+
+
 def onehot(idx64: torch.Tensor, K: int) -> torch.Tensor:
     """Dense [N, K] fp32 one-hot matrix (vqvae/ema_vector_quantizer.py:54-55)."""
     lib = _lib.load()
