@@ -247,6 +247,9 @@ int vq_pairwise_stats(const float* E, const float* image, const float* e2, int K
 int vq_pack_dist_index(const float* dmin, const int64_t* idx64, int64_t N, int64_t* packed, void* stream);
 int vq_unpack_dist_index(const int64_t* packed, int64_t N, float* dmin, int64_t* idx64, int32_t* idx32,
                          void* stream);
+/* acc[n] = min(acc[n], other[n]) over packed keys: merges the winners of two codebook-row ranges
+ * on one device (what the MIN all-reduce does across devices). */
+int vq_packed_min(int64_t* acc, const int64_t* other, int64_t N, void* stream);
 
 #ifdef __cplusplus
 }

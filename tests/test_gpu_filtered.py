@@ -154,3 +154,28 @@ def test_filtered_shard_search_with_code_base(dev):
         pb = ops.pack_dist_index(b["dmin"], b["indices"])
         assert torch.equal(pa, pb)
         assert int(b["indices"].min()) >= lo and int(b["indices"].max()) < lo + 1024
+
+
+def test_filtered_large_codebook_in_ranges(dev):
+    """K above the 8192 codes of one filtered launch: ranges of rows are searched one after the
+    other and merged through the packed keys; the result equals the fp32 search of the whole
+    codebook, duplicates across ranges and a NaN row included."""
+    from vq_vae_amd import ops
+    K, D = 20000, 64
+    E = gauss(460, (K, D))
+    E[15000] = E[77]                                       # exact tie across two ranges -> lowest index
+    z = gauss(461, (16, D, 32, 32))
+    z[0, :, 0, 0] = E[77]
+    z[1, 4, 2, 2] = np.nan
+    zt, Et = torch.from_numpy(z).to(dev), torch.from_numpy(E).to(dev)
+    ws = ops.Workspace(dev)
+    a = ops.search(zt, Et, ws, want_dmin=True)
+    ai, ad, aq = a["indices"].clone(), a["dmin"].clone(), a["quantized"].clone()
+    b = ops.search(zt, Et, ws, want_dmin=True, filtered=True)
+    torch.cuda.synchronize()
+    assert torch.equal(ai, b["indices"])
+    assert torch.equal(ad.view(torch.int32), b["dmin"].view(torch.int32))
+    assert torch.equal(aq.view(torch.int32), b["quantized"].view(torch.int32))
+    assert int(ai[0]) == 77
+    idx_o, _ = vo.search(z, E)
+    assert np.array_equal(b["indices"].cpu().numpy(), idx_o)

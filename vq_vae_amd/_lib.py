@@ -62,6 +62,7 @@ SIGNATURES = {
     "vq_pairwise_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p]),
     "vq_pack_dist_index": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "vq_packed_min": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "vq_unpack_dist_index": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 

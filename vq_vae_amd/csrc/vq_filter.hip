@@ -297,22 +297,13 @@ __global__ __launch_bounds__(512, 2) void vqf_filter_kernel(FilterArgs a) {
       for (int i = 0; i < 16; ++i) { c0[i] = 0.0f; c1[i] = 0.0f; }
 #pragma unroll
       for (int s = 0; s < FS; ++s) {
-#ifdef VQF_ABLATE_LDS
-        const bf16x8 af = __builtin_bit_cast(bf16x8, zb[1][(s + t) % FS]);
-#else
         const bf16x8 af = __builtin_bit_cast(bf16x8, A[(t * FS + s) * 64]);
-#endif
         c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, zb[0][s]), c0, 0, 0, 0);
         c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, zb[1][s]), c1, 0, 0, 0);
       }
       const uint32_t tilebits = (uint32_t)(st * FQ_STAGE_TILES + t) << 4;
-#ifdef VQF_ABLATE_SCAN
-      m[0][0] = __builtin_fminf(m[0][0], c0[0] + c0[5]);
-      m[1][0] = __builtin_fminf(m[1][0], c1[0] + c1[5]);
-#else
       fq_scan<R>(c0, tilebits, maskv, m[0]);
       fq_scan<R>(c1, tilebits, maskv, m[1]);
-#endif
     }
     __syncthreads();  // every wave is done with buf; the DMA of stage st+1 has landed
     cur ^= 1;
@@ -556,20 +547,6 @@ int vq_filter_prep(const float* E, const float* e2, int K, int D, void* fimage, 
 
 // Work buffer: [keys of pass 1: N x 32][row terms: N x 16][list A: N x 4][keys of pass 2: N x 64][row terms: N x 16][list B: N x 4]
 size_t vq_filter_work_bytes(int64_t N) { return N > 0 ? (size_t)N * 136 : 256; }
-
-// Internal (benchmarks): the first-pass filter kernel alone.
-int vq_filter_only_launch(const float* z, int nchw, int64_t N, int D, int64_t HW, const void* fimage, int K,
-                          int32_t* control, void* work, void* stream) {
-  const int tiles = fq_tiles(K);
-  FilterArgs f{};
-  f.z = z; f.image = static_cast<const u32x4*>(fimage);
-  f.hdr = reinterpret_cast<const uint32_t*>(static_cast<const char*>(fimage) + (size_t)tiles * fq_steps(D) * 1024);
-  f.N = N; f.HW = nchw ? HW : 1; f.nstages = tiles / FQ_STAGE_TILES;
-  f.cand = static_cast<u32x4*>(work);
-  f.rowaux = reinterpret_cast<f32x4*>(static_cast<char*>(work) + (size_t)N * 32);
-  f.control = control;
-  return dispatch_filter<4>(f, D, nchw != 0, (hipStream_t)stream);
-}
 
 // Internal: filter + verify, two levels.  Settled rows get idx / dmin; rows for the exact kernel
 // are appended to nf_rows (control[VQ_CTL_NF_COUNT]); rows that overflowed both levels are left

@@ -179,6 +179,17 @@ __global__ __launch_bounds__(256) void vq_unpack_kernel(const int64_t* __restric
   if (idx32) idx32[i] = (int32_t)id;
 }
 
+// acc[n] = min(acc[n], other[n]) over packed (distance, index) keys: the single-device form of the
+// MIN all-reduce that merges codebook-row shards.
+__global__ __launch_bounds__(256) void vq_packed_min_kernel(int64_t* __restrict__ acc, const int64_t* __restrict__ other,
+                                                            int64_t N) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n < N) {
+    const int64_t a = acc[n], b = other[n];
+    acc[n] = b < a ? b : a;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -215,6 +226,13 @@ int vq_pack_dist_index(const float* dmin, const int64_t* idx64, int64_t N, int64
   if (!dmin || !idx64 || !packed || N <= 0) return VQ_ERR_INVALID_ARG;
   hipLaunchKernelGGL(vq_pack_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dmin, idx64,
                      N, packed);
+  return vq_hip_status(hipGetLastError());
+}
+
+int vq_packed_min(int64_t* acc, const int64_t* other, int64_t N, void* stream) {
+  if (!acc || !other || N <= 0) return VQ_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(vq_packed_min_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, acc,
+                     other, N);
   return vq_hip_status(hipGetLastError());
 }
 

@@ -105,6 +105,40 @@ def filter_supported(K: int, D: int, temperature: float, code_base: int, want_qu
             and not (want_quantized and code_base != 0))
 
 
+FILTER_MAX_CODES = 8192   # codes per filtered launch (12 position bits in a key)
+
+
+def _search_filtered_chunked(z, E, ws: Workspace, temperature: float, code_base: int, want_quantized: bool,
+                             want_dmin: bool, events):
+    """Filtered search of a codebook with more than FILTER_MAX_CODES rows: one filtered launch per
+    range of rows, the ranges' winners merged through the packed (distance, index) keys -- the
+    merge of codebook-row shards, on one device."""
+    lib = _lib.load()
+    K, D = E.shape
+    if events is not None:
+        events[0].record(torch.cuda.current_stream(z.device))
+    best = None
+    r = None
+    for lo in range(0, K, FILTER_MAX_CODES):
+        r = search(z, E[lo: lo + FILTER_MAX_CODES], ws, temperature=temperature, code_base=code_base + lo,
+                   want_quantized=False, want_dmin=True, filtered=True)
+        packed = pack_dist_index(r["dmin"], r["indices"])
+        if best is None:
+            best = packed
+        else:
+            check(lib.vq_packed_min(_ptr(best), _ptr(packed), best.numel(), _stream(z.device)), "vq_packed_min")
+    dmin, idx64, idx32 = unpack_dist_index(best, ws, want_dmin=want_dmin)
+    q = lp = None
+    n_partial = 0
+    if want_quantized:
+        q, lp, n_partial = gather_st(z, E, idx64, ws)
+    if events is not None:
+        events[1].record(torch.cuda.current_stream(z.device))
+    return {"indices": idx64, "idx32": idx32, "dmin": dmin, "quantized": q, "loss_partial": lp,
+            "n_partial": n_partial, "layout": r["layout"], "N": r["N"], "HW": r["HW"], "control": r["control"],
+            "zmax_valid": True}
+
+
 def search(z: torch.Tensor, E: torch.Tensor, ws: Workspace, temperature: float = 1.0, code_base: int = 0,
            want_quantized: bool = True, want_dmin: bool = False, exact: bool = False, prepared=None,
            events=None, allow_split: bool = True, filtered: bool = False):
@@ -121,6 +155,9 @@ def search(z: torch.Tensor, E: torch.Tensor, ws: Workspace, temperature: float =
     E = _f32c(E, "codebook")
     K, D = E.shape
     layout, N, HW = _shape_of(z, D)
+    if (filtered and not exact and K > FILTER_MAX_CODES
+            and filter_supported(FILTER_MAX_CODES, D, float(temperature), code_base, want_quantized)):
+        return _search_filtered_chunked(z, E, ws, float(temperature), code_base, want_quantized, want_dmin, events)
     image, e2, control = prepared if prepared is not None else prepare_codebook(E, ws)
     dev = z.device
     idx64 = torch.empty(N, dtype=torch.int64, device=dev)
