@@ -102,11 +102,13 @@ def test_filtered_module_step_matches_fp32(dev):
     from vq_vae_amd import EMAVectorQuantizer
     K, D = 1024, 64
     E = gauss(430, (K, D)) * np.float32(0.5)
-    z = torch.from_numpy(gauss(431, (40, D, 32, 32))).to(dev)        # 40960 rows >= filtered_min_rows
+    z = torch.from_numpy(gauss(431, (64, D, 32, 32))).to(dev)        # 65536 rows, 2^32 work: lower the work bar
     res = {}
     for mode in ("fp32", "filtered"):
         m = EMAVectorQuantizer(K, D, 3.0).to(dev)
         m.search_mode = mode
+        m.filtered_min_work = 1 << 30
+        assert m._use_filter(z) == (mode == "filtered")
         with torch.no_grad():
             m.embedding.weight.copy_(torch.from_numpy(E))
         m.train()

@@ -101,8 +101,10 @@ class EMAVectorQuantizer(nn.Module):
     #: evaluated in fp32 -- the same indices, distances and outputs bit for bit, several times faster
     #: on large batches; shapes it does not cover (D not in {64,128,256}, K > 8192) use "fp32".
     search_mode = "fp32"
-    #: below this many latent vectors "filtered" has nothing to gain and the fp32 search runs
-    filtered_min_rows = 32768
+    #: "filtered" pays from about this many latent vectors and this much work (rows x codes x channels)
+    #: upwards -- its pipeline of kernels has a floor of ~0.4 ms; below either, the fp32 search runs
+    filtered_min_rows = 65536
+    filtered_min_work = 1 << 35
 
     def __init__(self, num_embeddings, embedding_dim, commitment_cost, decay=0.95, epsilon=1e-5):
         super().__init__()
@@ -153,7 +155,9 @@ class EMAVectorQuantizer(nn.Module):
     def _use_filter(self, z: torch.Tensor) -> bool:
         if self.search_mode not in ("fp32", "filtered"):
             raise ValueError(f"search_mode must be 'fp32' or 'filtered', got {self.search_mode!r}")
-        return self.search_mode == "filtered" and z.numel() // self.embedding_dim >= self.filtered_min_rows
+        rows = z.numel() // self.embedding_dim
+        return (self.search_mode == "filtered" and rows >= self.filtered_min_rows
+                and rows * self.num_embeddings * self.embedding_dim >= self.filtered_min_work)
 
     def _run_step(self, z: torch.Tensor, temperature: float) -> ops.StepResult:
         E = self.embedding.weight.data
