@@ -167,3 +167,27 @@ def test_stats_json_schema():
                               "index_counts", "probs"]
     import json
     json.dumps(d)
+
+
+def test_filtered_entry_argument_checks():
+    """vq_search_filtered rejects bad arguments and unsupported shapes before any GPU work
+    (status codes only; no device is touched on these paths)."""
+    from vq_vae_amd import _lib
+    lib = _lib.load()
+    p = ctypes.c_void_p(0x1000)          # never dereferenced on the paths below
+    nul = ctypes.c_void_p(0)
+
+    def call(z=p, N=1024, D=64, K=512, T=1.0, layout=0, hw=1, q=nul, code_base=0):
+        return lib.vq_search_filtered(z, layout, N, D, hw, p, p, p, p, K, T, code_base, p, p, nul, q, nul, p, p, p, nul)
+
+    assert call(z=nul) != 0 and b"invalid" in lib.vq_status_string(call(z=nul))
+    assert call(N=0) == call(z=nul)
+    assert call(layout=7) == call(z=nul)
+    assert call(layout=1, hw=100) == call(z=nul)                     # N not a multiple of H*W
+    unsupported = call(K=16384)
+    assert unsupported != 0 and unsupported != call(z=nul)
+    assert call(D=32) == unsupported and call(T=0.0) == unsupported and call(T=float("inf")) == unsupported
+    assert call(q=p, code_base=512) == unsupported
+    assert lib.vq_filter_work_bytes(1000) == 136 * 1000
+    assert lib.vq_filter_image_bytes(8192, 256) == 256 * 17 * 1024 + 256 + 8192 * 16
+    assert lib.vq_filter_loss_partial_bytes(1 << 20) > lib.vq_loss_partial_bytes(1 << 20)
