@@ -2,19 +2,24 @@
 // vq_search.hip -- the argmin of the fp32 fma-chain distances of
 // vqvae/ema_vector_quantizer.py:42-53, lowest index on ties -- at bf16 matrix-core speed.
 //
-//   1. Filter (vqf_filter_kernel).  Approximate distances a[n,k] = c_n + ||e_k||^2 - 2 z~.e~ from
-//      bf16-rounded operands on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate).  The same
-//      z-stationary layout as the fp32 kernel: latents in registers as the B operand, the bf16
-//      codebook image streamed through LDS by DMA, 16 approximate distances of one latent per lane.
-//      Each lane keeps the R smallest keys it has seen; a key is the distance with its low 12 bits
-//      replaced by the code's position, so a min / median-of-three pair keeps value and index at once.
-//   2. Verify (vqf_verify_kernel).  |a - (d + c_n)| <= delta_n is a rigorous bound (below), so only
-//      codes whose key lies within 2 delta_n (+ the key truncation) of the smallest key can be the
-//      fp32 argmin.  These few candidates are evaluated with the exact fp32 chain, in the order the
-//      fp32 MFMA and the CPU oracle use, and the smallest (lowest index on ties) wins.
-//   3. Rows whose candidate list may be incomplete (all R keys of a lane inside the band), rows
-//      that are not finite or degenerate, and every row of a non-finite codebook are handed to the
-//      exact scalar kernel through the same list the fp32 path uses.
+//   1. Filter (vqf_filter_kernel).  Approximate distances from bf16-rounded operands on
+//      v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate), in the z-stationary layout of the fp32
+//      kernel: latents in registers as the B operand, the bf16 codebook image streamed through LDS
+//      by DMA, 16 values of one latent per lane and 32-code tile.  What the matrix core accumulates
+//      is a lower bound L[n,k] of the (shifted) fp32 distance -- see "Error bound" -- and each lane
+//      keeps the R smallest keys it has seen; a key is L with its low 12 bits replaced by the code's
+//      position in the sweep, so one and-or, one unsigned min and R-1 medians-of-three per value
+//      maintain values and indices together.
+//   2. Verify (vqf_verify_kernel).  Only codes whose key lies below a threshold derived from the
+//      smallest key can be the fp32 argmin.  These few candidates (1.6 per row on Gaussian data) are
+//      evaluated with the exact fp32 chain, in the order the fp32 MFMA and the CPU oracle use, and
+//      the smallest (lowest index on ties) wins.
+//   3. A row whose list may be incomplete (all R keys of a lane under the threshold) is filtered
+//      again with R = 8 (list mode); what is still open after that goes to a kernel that evaluates
+//      all codes for one row (vq_search.hip).  Rows that are not finite or degenerate, and every row
+//      of a non-finite codebook, are handed to the exact scalar kernel through the same list the
+//      fp32 path uses.  A batch whose first pass leaves more than N/8 rows open is finished by the
+//      fp32 MFMA kernel.  All of this is decided on the device from counters.
 //
 // Error bound.  With z = z~ + dz and e = e~ + de (bf16 round-to-nearest),
 //   z.e - z~.e~ = z~.de + dz.e, so |2 z.e - 2 z~.e~| <= 2 (||z~|| ||de_k|| + ||dz|| ||e_k||)
