@@ -168,23 +168,25 @@ def main() -> None:
         return ops.quantize_step(z, E, ema_w, cs, usage, beta=BETA, decay=DECAY, epsilon=EPS, temperature=1.0,
                                  training=True, ws=ws, stats_reduce=stats_reduce, search_events=ev, filtered=filtered)
 
-    def timed_run(filtered: bool) -> float:
-        """W untimed + K timed steps, barrier + synchronize on both sides, max over ranks (seconds)."""
+    def timed_run(filtered: bool, across_ranks: bool = True) -> float:
+        """W untimed + K timed steps, barrier + synchronize on both sides, max over ranks (seconds).
+        across_ranks=False times this rank alone (no barrier / max; the step's own all-reduce stays)."""
+        sync = world > 1 and across_ranks
         for _ in range(args.warmup):
             step(False, filtered)
         torch.cuda.synchronize()
-        if world > 1:
+        if sync:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step(True, filtered)
         torch.cuda.synchronize()
-        if world > 1:
+        if sync:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if sync:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -202,24 +204,29 @@ def main() -> None:
 
     # the same step with the filtered search (bf16 matrix-core filter + exact fp32 verification of the
     # surviving candidates): identical outputs, reported beside the fp32 headline, never as `value`
-    filt = None
-    if not args.no_filtered:
-        ev_fp32 = list(ev_pairs)
+    def filtered_extra() -> dict:
         ev_pairs.clear()
         E.copy_(E0); ema_w.zero_(); cs.zero_(); usage.zero_()
         ref = ops.search(z, E, ws, want_quantized=False)["indices"].clone()
         got = ops.search(z, E, ws, want_quantized=False, filtered=True)["indices"]
         same = bool(torch.equal(ref, got))
         del ref, got
-        f_elapsed = timed_run(True)
+        f_elapsed = timed_run(True, across_ranks=False)   # rank-local clock: nothing here may deadlock the job
         f_search_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_pairs]))
-        filt = {"value": rows * world * args.steps / f_elapsed, "unit": "vectors/s",
+        return {"value": rows * world * args.steps / f_elapsed, "unit": "vectors/s",
                 "ms_per_step": f_elapsed / args.steps * 1e3, "search_ms": f_search_ms,
                 "indices_identical_to_fp32_search": same, "rows_compared": rows,
                 "effective_tflops": 2.0 * rows * K * D / (f_search_ms * 1e-3) / 1e12,
+                "timing": "max over ranks" if world == 1 else "rank 0 only",
                 "note": "opt-in search_mode='filtered': bf16 MFMA pass under a proven error bound selects the candidates, "
                         "fp32 chain decides; outputs bit-identical to the fp32 search"}
-        ev_pairs[:] = ev_fp32
+
+    filt = None
+    if not args.no_filtered:
+        try:
+            filt = filtered_extra()
+        except Exception as exc:  # the extra must never cost the headline line
+            filt = {"error": f"{type(exc).__name__}: {exc}"}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -252,7 +259,10 @@ def main() -> None:
             line["filtered_search"] = filt
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
-            line["parity"] = parity_gate(z, E0)
+            try:
+                line["parity"] = parity_gate(z, E0)
+            except Exception as exc:
+                line["parity"] = {"error": f"{type(exc).__name__}: {exc}"}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
