@@ -188,6 +188,6 @@ def test_filtered_entry_argument_checks():
     assert unsupported != 0 and unsupported != call(z=nul)
     assert call(D=32) == unsupported and call(T=0.0) == unsupported and call(T=float("inf")) == unsupported
     assert call(q=p, code_base=512) == unsupported
-    assert lib.vq_filter_work_bytes(1000) == 136 * 1000
-    assert lib.vq_filter_image_bytes(8192, 256) == 256 * 17 * 1024 + 256 + 8192 * 16
+    assert lib.vq_filter_work_bytes(1000) == 168 * 1000 and lib.vq_filter_work_bytes(1001) == 168 * 1004
+    assert lib.vq_filter_image_bytes(8192, 256) == 256 * 17 * 1024 + 256 + 8192 * 32 + 256 * 4 * 33
     assert lib.vq_filter_loss_partial_bytes(1 << 20) > lib.vq_loss_partial_bytes(1 << 20)

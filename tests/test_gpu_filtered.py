@@ -40,6 +40,7 @@ def _same_bits(a, b):
     (512, 64, (16, 64, 16, 16), 1.0),          # benchmark config 1
     (1000, 64, (4, 64, 16, 16), 1.0),          # K not a multiple of the 128-code stage
     (512, 128, (5000, 128), 1.0),              # (N, D) layout, ragged row count
+    (640, 64, (4999, 64), 1.0),                # row count not a multiple of 4
     (8192, 256, (8, 256, 32, 32), 1.0),        # benchmark config 2 shape
     (8192, 256, (8, 256, 32, 32), 2.5),        # temperature
     (300, 256, (1, 256, 7, 9), 0.7),
@@ -181,3 +182,20 @@ def test_filtered_large_codebook_in_ranges(dev):
     assert int(ai[0]) == 77
     idx_o, _ = vo.search(z, E)
     assert np.array_equal(b["indices"].cpu().numpy(), idx_o)
+
+
+def test_filtered_is_translation_invariant(dev):
+    """A large common offset of latents and codes (5 sigma per channel) must not push the batch to
+    the fp32 fall-back: the filter centres its operands on the codebook mean."""
+    from vq_vae_amd import ops
+    K, D = 2048, 64
+    mu = (5.0 * gauss(470, (D,))).astype(np.float32)
+    E = gauss(471, (K, D)) + mu
+    z = gauss(472, (64, D, 32, 32)) + mu.reshape(1, D, 1, 1)
+    o = _both(z, E, dev)
+    idx_o, dmin_o = vo.search(z, E)
+    assert np.array_equal(o["filtered"][0], idx_o)
+    assert _same_bits(o["filtered"][1], np.asarray(dmin_o, np.float32))
+    assert _same_bits(o["filtered"][2], o["fp32"][2])
+    unsettled = int(o["filtered"][4][4])
+    assert unsettled * 8 <= z.shape[0] * 32 * 32, unsettled      # no fall-back

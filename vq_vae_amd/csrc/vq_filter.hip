@@ -21,24 +21,27 @@
 //      fp32 path uses.  A batch whose first pass leaves more than N/8 rows open is finished by the
 //      fp32 MFMA kernel.  All of this is decided on the device from counters.
 //
-// Error bound.  With z = z~ + dz and e = e~ + de (bf16 round-to-nearest),
-//   z.e - z~.e~ = z~.de + dz.e, so |2 z.e - 2 z~.e~| <= 2 (||z~|| ||de_k|| + ||dz|| ||e_k||)
-// by Cauchy-Schwarz; ||dz||, ||z~|| are computed per row and ||de_k||, ||e_k|| per code from the
-// actual rounding errors.  Products of two bf16 are exact in fp32; the fp32 accumulation of the
-// matrix core and the rounding of the fp32 chain itself are covered by (D + 16) 2^-21 times the
-// sum of the magnitudes, (||z|| + ||e_k||)^2 on either side (the chain needs (D + 2) 2^-24 of it;
-// the rest allows the matrix core 7 ulp per accumulated product).  All of it is linear in three
-// per-code numbers with per-row coefficients,
-//   delta[n,k] = const_n + c1_n ||de_k|| + c2_n ||e_k|| + c3_n ||e_k||^2,
-// so the matrix core subtracts the code-dependent part itself: three more slots of the extra
-// k-step hold (||de_k||, ||e_k||, ||e_k||^2) against (-c1_n, -c2_n, -c3_n), all rounded up in
-// magnitude to bf16, and a key is a LOWER bound L[n,k] of d + c_n - const_n.  With k^ the code of
-// the smallest key, every code that can be the fp32 argmin has
+// Error bound.  The filter works on centred data, z' = fl(z - mu), e' = fl(e - mu) with mu the
+// codebook's mean row (distances do not change under a common shift; a common offset of the data
+// would otherwise eat the bf16 mantissa).  With z' = z~ + dz and e' = e~ + de (bf16 round-to-nearest),
+//   z'.e' - z~.e~ = z~.de + dz.e', so |2 z'.e' - 2 z~.e~| <= 2 (||z~|| ||de_k|| + ||dz|| ||e'_k||)
+// by Cauchy-Schwarz; ||dz||, ||z~|| are computed per row and ||de_k||, ||e'_k|| per code from the
+// actual rounding errors.  Products of two bf16 are exact in fp32.  The fp32 accumulation of the
+// matrix core, the roundings of the centring and of ||e'_k||^2 are covered by g_f = (D + 24) 2^-21
+// times the magnitudes on the filter's side, (||z'|| + ||e'_k||)^2 (this allows the matrix core 7 ulp
+// per accumulated product); the roundings of the fp32 chain itself by g_o = (D + 4) 2^-24 times
+// (||z|| + ||e_k||)^2, uncentred.  All of it is linear in five per-code numbers with per-row
+// coefficients,
+//   delta[n,k] = const_n + c1 ||de_k|| + c2 ||e'_k|| + c3 ||e'_k||^2 + c4 ||e_k|| + c5 ||e_k||^2,
+// so the matrix core subtracts the code-dependent part itself: five more slots of the extra k-step
+// hold the per-code numbers against (-c1 .. -c5), all rounded up in magnitude to bf16, and a key
+// is a LOWER bound L[n,k] of d + c_n - const_n.  With k^ the code of the smallest key, every code
+// that can be the fp32 argmin has
 //   L[n,k] <= L[n,k^] + 2 (delta[n,k^] - const_n) + 2 const_n        (+ the key truncation),
-// so a code pays for its own norm only and the threshold for the best code's.
-// ||e_k||^2 itself enters the contraction exactly, as three bf16 terms times 1.0, and
-// c_n >= ||z||^2 + max_k delta[n,k] (rounded up to bf16, times 1.0) keeps every key positive, so
-// that keys order as unsigned integers and as floats alike.
+// so a code pays for its own norms only and the threshold for the best code's.
+// ||e'_k||^2 itself enters the contraction as three bf16 terms times 1.0 (exactly the fp32 number
+// the preparation computed), and c_n >= ||z'||^2 + max_k delta[n,k] (rounded up to bf16, times
+// 1.0) keeps every key positive, so that keys order as unsigned integers and as floats alike.
 #include "vq_common.h"
 
 namespace {
@@ -69,25 +72,59 @@ __host__ __device__ inline int fq_steps(int D) { return D / 16 + 1; }
 __host__ __device__ inline int fq_tiles(int K) { return (K + 32 * FQ_STAGE_TILES - 1) / (32 * FQ_STAGE_TILES) * FQ_STAGE_TILES; }
 
 // ---------------------------------------------------------------------------------------
-// bf16 codebook image: [tile][step][lane] fragments of 8 bf16.  Lane (i, g) of step s holds
-// -2 e~[32 tile + i][16 s + 8 g + 0..7]; the last step holds (e2_hi, e2_mid, e2_lo, 1, ||de||, ||e||,
-// ||e||^2, 0) in the g = 0 lanes, the last three rounded up to bf16 and also stored as floats in
-// aux[code] for the verification.  hdr[0..2] = max of those three (bit patterns, atomicMax).
+// mu[c] = mean over the codes of E[k][c], in two steps with a fixed summation order: 32 row
+// ranges x D/64 channel groups of partial sums (coalesced 256-byte row segments), then one thread
+// per channel adds the 32 partials.  Any mu is valid for the filter; this one is reproducible.
+// ---------------------------------------------------------------------------------------
+constexpr int FQ_MEAN_PARTS = 32;
+
+__global__ __launch_bounds__(256) void vqf_mean_partial_kernel(const float* __restrict__ E, int K, int D,
+                                                               float* __restrict__ partial) {
+  __shared__ float part[4][64];
+  const int cl = threadIdx.x & 63, r = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int per = (K + FQ_MEAN_PARTS - 1) / FQ_MEAN_PARTS;
+  const int k0 = blockIdx.y * per, k1 = k0 + per < K ? k0 + per : K;
+  float acc = 0.0f;
+  if (c < D)
+    for (int k = k0 + r; k < k1; k += 4) acc += E[(size_t)k * D + c];
+  part[r][cl] = acc;
+  __syncthreads();
+  if (r == 0 && c < D) partial[blockIdx.y * D + c] = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+}
+
+__global__ __launch_bounds__(256) void vqf_mean_final_kernel(const float* __restrict__ partial, int K, int D,
+                                                             float* __restrict__ mu) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= D) return;
+  float acc = 0.0f;
+  for (int p = 0; p < FQ_MEAN_PARTS; ++p) acc += partial[p * D + c];
+  mu[c] = acc / (float)K;
+}
+
+// ---------------------------------------------------------------------------------------
+// bf16 codebook image: [tile][step][lane] fragments of 8 bf16.  With e' = fl(e - mu): lane (i, g)
+// of step s holds -2 e~'[32 tile + i][16 s + 8 g + 0..7]; the last step holds (n2_hi, n2_mid, n2_lo,
+// 1, ||de||, ||e'||, ||e'||^2, ||e||) in the g = 0 lanes and (||e||^2, 0...) in the g = 1 lanes, where
+// n2 = ||e'||^2 as summed here and the five norms are rounded up to bf16; they are also stored as
+// floats in aux[2 code], aux[2 code + 1] for the verification.  hdr[0..4] = their maxima (bit
+// patterns, atomicMax).
 // ---------------------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(64) void vqf_prep_kernel(const float* __restrict__ E, const float* __restrict__ e2, int K,
-                                                      u32x4* __restrict__ image, uint32_t* __restrict__ hdr,
-                                                      f32x4* __restrict__ aux) {
+                                                      const float* __restrict__ mu, u32x4* __restrict__ image,
+                                                      uint32_t* __restrict__ hdr, f32x4* __restrict__ aux) {
   constexpr int FS = D / 16 + 1;
   const int lane = threadIdx.x, i = lane & 31, g = lane >> 5;
   const int tile = blockIdx.x, code = tile * 32 + i;
   const bool real = code < K;
   const f32x4* row = reinterpret_cast<const f32x4*>(E + (size_t)(real ? code : 0) * D);
+  const f32x4* mrow = reinterpret_cast<const f32x4*>(mu);
   u32x4* dst = image + (size_t)tile * FS * 64 + lane;
   float en = 0.0f, de = 0.0f;
 #pragma unroll
   for (int s = 0; s < D / 16; ++s) {
-    f32x4 v0 = row[4 * s + 2 * g], v1 = row[4 * s + 2 * g + 1];
+    f32x4 v0 = row[4 * s + 2 * g] - mrow[4 * s + 2 * g], v1 = row[4 * s + 2 * g + 1] - mrow[4 * s + 2 * g + 1];
     if (!real) { v0 = f32x4{0, 0, 0, 0}; v1 = f32x4{0, 0, 0, 0}; }
     const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
     u32x4 o;
@@ -105,28 +142,37 @@ __global__ __launch_bounds__(64) void vqf_prep_kernel(const float* __restrict__ 
   }
   en += __shfl_xor(en, 32);
   de += __shfl_xor(de, 32);
+  // per-code terms of the error bound, rounded up to bf16 (padding codes: 0, they never win)
+  float raw = real ? e2[code] : 0.0f;                   // ||e||^2, uncentred, as the fp32 chain uses it
+  if (!(raw <= VQ_NORM_LIMIT)) raw = VQ_NORM_LIMIT;     // non-finite codebooks take the exact kernel anyway
+  const float pde = real ? bf16_up(__builtin_sqrtf(de) * 1.0001f) : 0.0f;
+  const float pen = real ? bf16_up(__builtin_sqrtf(en) * 1.0001f) : 0.0f;
+  const float pe2 = real ? bf16_up(en * 1.0001f) : 0.0f;
+  const float pun = bf16_up(__builtin_sqrtf(raw) * 1.0001f);
+  const float pu2 = bf16_up(raw * 1.0001f);
   u32x4 o = u32x4{0, 0, 0, 0};
   if (g == 0) {
-    float n2 = real ? e2[code] : FQ_PAD_NORM;
-    if (!(n2 <= FQ_PAD_NORM)) n2 = FQ_PAD_NORM;  // non-finite codebooks take the exact kernel anyway
+    float n2 = real ? en : FQ_PAD_NORM;
+    if (!(n2 <= FQ_PAD_NORM)) n2 = FQ_PAD_NORM;
     const float hi = __uint_as_float(__float_as_uint(n2) & 0xffff0000u);
     const float r1 = n2 - hi;
     const float mid = __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
     const float lo = r1 - mid;
-    // per-code terms of the error bound, rounded up to bf16 (padding codes: 0, they never win)
-    const float pde = real ? bf16_up(__builtin_sqrtf(de) * 1.0001f) : 0.0f;
-    const float pen = real ? bf16_up(__builtin_sqrtf(en) * 1.0001f) : 0.0f;
-    const float pe2 = real ? bf16_up(en * 1.0001f) : 0.0f;
     o[0] = bf16_pair(hi, mid);
     o[1] = bf16_pair(lo, 1.0f);
     o[2] = bf16_pair(pde, pen);
-    o[3] = bf16_pair(pe2, 0.0f);
-    aux[code] = f32x4{pde, pen, pe2, 0.0f};
+    o[3] = bf16_pair(pe2, pun);
+    aux[2 * code] = f32x4{pde, pen, pe2, pun};
+    aux[2 * code + 1] = f32x4{pu2, 0.0f, 0.0f, 0.0f};
     if (real) {
       atomicMax(&hdr[0], __float_as_uint(pde));
       atomicMax(&hdr[1], __float_as_uint(pen));
       atomicMax(&hdr[2], __float_as_uint(pe2));
+      atomicMax(&hdr[3], __float_as_uint(pun));
+      atomicMax(&hdr[4], __float_as_uint(pu2));
     }
+  } else {
+    o[0] = bf16_pair(pu2, 0.0f);
   }
   dst[(D / 16) * 64] = o;
 }
@@ -135,11 +181,12 @@ struct FilterArgs {
   const float* z;
   const u32x4* image;
   const uint32_t* hdr;
+  const float* mu;   // [D] centre of the codebook
   int64_t N;
   int64_t HW;
   int nstages;
   u32x4* cand;     // [rows][2][R/4] : the R smallest keys of each lane half (unused slots +inf)
-  f32x4* rowaux;   // [rows] : const_n, c1_n, c2_n, c3_n of the error bound (c's as rounded to bf16)
+  f32x4* rowaux;   // [rows][2] : const_n, c1 .. c5 of the error bound (c's as rounded to bf16)
   int32_t* control;
   // list mode: the launch covers rows row_list[0 .. control[count_word]); cand / rowaux are indexed
   // by the position in the list
@@ -207,20 +254,29 @@ __global__ __launch_bounds__(512, 2) void vqf_filter_kernel(FilterArgs a) {
 
   fq_stage_copy<D>(a.image, 0, flds, wave, lane);
 
-  const float demax = __uint_as_float(a.hdr[0]), emax = __uint_as_float(a.hdr[1]), e2max = __uint_as_float(a.hdr[2]);
+  // the codebook mean, through LDS (behind the two stage buffers)
+  float* mus = reinterpret_cast<float*>(flds + 2 * STAGE_B);
+  if (threadIdx.x < D) mus[threadIdx.x] = a.mu[threadIdx.x];
+  __syncthreads();
+
+  float hmax[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) hmax[i] = __uint_as_float(a.hdr[i]);
 
   u32x4 zb[2][FS];
-  f32x4 rowaux[2];
-  uint32_t zmax_bits = 0;
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) {
     int64_t n = row0 + ct * 32 + j;
     if (n >= nrows) n = nrows - 1;
     if (listed) n = a.row_list[n];
-    float zt2 = 0.0f, dz2 = 0.0f;
-    uint32_t am = 0;
+    float zt2 = 0.0f, dz2 = 0.0f, zu2 = 0.0f;
 #pragma unroll
     for (int s = 0; s < ZS; ++s) {
+      // keep at most four steps' loads in flight: more would not fit the register file
+      if ((s & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+      const f32x4* mp = reinterpret_cast<const f32x4*>(mus + 16 * s + 8 * g);
+      const f32x4 m0 = mp[0], m1 = mp[1];
+      const float mc[8] = {m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2], m1[3]};
       float v[8];
       if (NCHW) {
         const int64_t b = n / a.HW, hw = n - b * a.HW;
@@ -234,6 +290,11 @@ __global__ __launch_bounds__(512, 2) void vqf_filter_kernel(FilterArgs a) {
         v[4] = x1[0]; v[5] = x1[1]; v[6] = x1[2]; v[7] = x1[3];
       }
 #pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        zu2 = __builtin_fmaf(v[i], v[i], zu2);
+        v[i] = v[i] - mc[i];                               // centred
+      }
+#pragma unroll
       for (int p = 0; p < 4; ++p) {
         const uint32_t w = bf16_pair(v[2 * p], v[2 * p + 1]);
         zb[ct][s][p] = w;
@@ -243,43 +304,45 @@ __global__ __launch_bounds__(512, 2) void vqf_filter_kernel(FilterArgs a) {
         zt2 = __builtin_fmaf(t1, t1, zt2);
         dz2 = __builtin_fmaf(r0, r0, dz2);
         dz2 = __builtin_fmaf(r1, r1, dz2);
-        const uint32_t a0 = __float_as_uint(v[2 * p]) & 0x7fffffffu, a1 = __float_as_uint(v[2 * p + 1]) & 0x7fffffffu;
-        am = a0 > am ? a0 : am;
-        am = a1 > am ? a1 : am;
       }
     }
-    zmax_bits = am > zmax_bits ? am : zmax_bits;
     zt2 += __shfl_xor(zt2, 32);
     dz2 += __shfl_xor(dz2, 32);
+    zu2 += __shfl_xor(zu2, 32);
     // coefficients of the error bound for this row (see the file comment)
     const float nz = __builtin_sqrtf(zt2) * 1.0001f, ndz = __builtin_sqrtf(dz2) * 1.0001f;
-    const float zc = nz + ndz;                                              // >= ||z||
-    const float gam = (float)(D + 16) * 4.76837158203125e-07f * 1.01f;      // (D + 16) 2^-21
+    const float zc = nz + ndz;                                              // >= ||z'||
+    const float zn = __builtin_sqrtf(zu2) * 1.0001f;                        // >= ||z||
+    const float gf = (float)(D + 24) * 4.76837158203125e-07f * 1.01f;       // (D + 24) 2^-21
+    const float go = (float)(D + 4) * 5.9604644775390625e-08f * 1.01f;      // (D + 4) 2^-24
     const float c1 = bf16_up(2.0f * nz * 1.0001f);                          // times ||de_k||
-    const float c2 = bf16_up((2.0f * ndz + 4.0f * gam * zc) * 1.0001f);     // times ||e_k||
-    const float c3 = bf16_up(2.0f * gam);                                   // times ||e_k||^2
-    const float wmax = (c1 * demax + c2 * emax + c3 * e2max) * 1.0001f;     // largest code-dependent part
-    const float cst = (gam * (2.0f * zc * zc * 1.0001f + 4.0f * wmax) + 1.0e-30f + nz * 1.0e-35f) * 1.001f;
-    rowaux[ct] = f32x4{cst, c1, c2, c3};
+    const float c2 = bf16_up((2.0f * ndz + 2.02f * gf * zc) * 1.0001f);     // times ||e'_k||
+    const float c3 = bf16_up(1.01f * gf);                                   // times ||e'_k||^2
+    const float c4 = bf16_up(2.0f * go * zn * 1.0001f);                     // times ||e_k||
+    const float c5 = bf16_up(go * 1.0001f);                                 // times ||e_k||^2
+    // largest code-dependent part over the codebook
+    const float wmax = (c1 * hmax[0] + c2 * hmax[1] + c3 * hmax[2] + c4 * hmax[3] + c5 * hmax[4]) * 1.0001f;
+    const float cst = (gf * (1.01f * zc * zc + 3.1f * wmax) + go * zn * zn * 1.0001f + 1.0e-30f + nz * 1.0e-35f) * 1.001f;
+    {
+      // written now rather than after the sweep: 16 registers less to carry through it
+      const int64_t pos = row0 + ct * 32 + j;
+      if (g == 0 && pos < nrows) {
+        a.rowaux[2 * pos] = f32x4{cst, c1, c2, c3};
+        a.rowaux[2 * pos + 1] = f32x4{c4, c5, 0.0f, 0.0f};
+      }
+    }
     const float cup = bf16_up(zc * zc * 1.0001f + (2.0f * wmax + cst) * 1.0001f);  // keeps every key positive
     u32x4 extra = u32x4{0, 0, 0, 0};
     if (g == 0) {
       extra[0] = bf16_pair(1.0f, 1.0f);
       extra[1] = bf16_pair(1.0f, cup);
       extra[2] = bf16_pair(-c1, -c2);
-      extra[3] = bf16_pair(-c3, 0.0f);
+      extra[3] = bf16_pair(-c3, -c4);
+    } else {
+      extra[0] = bf16_pair(-c5, 0.0f);
     }
     zb[ct][ZS] = extra;
   }
-  {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const uint32_t o = (uint32_t)__shfl_xor((int)zmax_bits, off);
-      zmax_bits = o > zmax_bits ? o : zmax_bits;
-    }
-    if (lane == 0 && zmax_bits) atomicMax(reinterpret_cast<unsigned int*>(&a.control[VQ_CTL_ZMAX]), zmax_bits);
-  }
-
   uint32_t maskv = FQ_KEY_MASK;
   asm volatile("" : "+v"(maskv));
   float m[2][R];
@@ -322,7 +385,6 @@ __global__ __launch_bounds__(512, 2) void vqf_filter_kernel(FilterArgs a) {
       for (int q = 0; q < R / 4; ++q)
         a.cand[(pos * 2 + g) * (R / 4) + q] = u32x4{__float_as_uint(m[ct][4 * q]), __float_as_uint(m[ct][4 * q + 1]),
                                                    __float_as_uint(m[ct][4 * q + 2]), __float_as_uint(m[ct][4 * q + 3])};
-      if (g == 0) a.rowaux[pos] = rowaux[ct];
     }
   }
 }
@@ -333,7 +395,7 @@ struct VerifyArgs {
   const float* e2;
   const u32x4* cand;
   const f32x4* rowaux;
-  const f32x4* aux;      // per-code (||de||, ||e||, ||e||^2) as the filter used them
+  const f32x4* aux;      // per-code norms as the filter used them: [2 k] = (||de||, ||e'||, ||e'||^2, ||e||), [2 k + 1] = (||e||^2, ..)
   int64_t N;
   int64_t HW;
   int K;
@@ -378,7 +440,7 @@ __global__ __launch_bounds__(256) void vqf_verify_kernel(VerifyArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) kh[g][4 * q + i] = v[i];
     }
-  const f32x4 ra = a.rowaux[pos];
+  const f32x4 ra = a.rowaux[2 * pos], rb = a.rowaux[2 * pos + 1];
   const float v0 = __uint_as_float(kh[0][0] & FQ_KEY_MASK), v1 = __uint_as_float(kh[1][0] & FQ_KEY_MASK);
   const int g0 = v1 < v0 ? 1 : 0;                 // half that holds the smallest key
   const float mn = g0 ? v1 : v0;
@@ -386,8 +448,8 @@ __global__ __launch_bounds__(256) void vqf_verify_kernel(VerifyArgs a) {
   // key truncation: value in (L (1 - 2^-11), L]
   int kbest = fq_decode(g0 ? kh[1][0] : kh[0][0], g0);
   if (kbest >= a.K) kbest = 0;                    // garbage keys (flagged codebook): the row goes to the exact kernel
-  const f32x4 ca = a.aux[kbest];
-  const float wbest = (ra[1] * ca[0] + ra[2] * ca[1] + ra[3] * ca[2]) * 1.0001f;
+  const f32x4 ca = a.aux[2 * kbest], cb = a.aux[2 * kbest + 1];
+  const float wbest = (ra[1] * ca[0] + ra[2] * ca[1] + ra[3] * ca[2] + rb[0] * ca[3] + rb[1] * cb[0]) * 1.0001f;
   const float thr = mn * 1.0009765625f + 2.0f * (wbest + ra[0]) * 1.0001f;
   if (!(thr < __builtin_inff()) || !(mn >= 0.0f)) exact_row = true;  // also catches NaN
   int code[SL];
@@ -428,13 +490,18 @@ __global__ __launch_bounds__(256) void vqf_verify_kernel(VerifyArgs a) {
   // the 64-byte sector fetched by the first serves the other three (rows of different lanes share
   // nothing, so a sector used once would cost four times the traffic).
   const int n16 = a.D / 16;
+  uint32_t zmax_bits = 0;  // max |z| (bit pattern) of this row, for the EMA scatter's fixed-point scale
   float zn[16];  // the next step's latent values are in flight while this step computes
 #pragma unroll
   for (int i = 0; i < 16; ++i) zn[i] = zrow[(int64_t)i * zst];
   for (int c16 = 0; c16 < n16; ++c16) {
     float zv[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) zv[i] = zn[i];
+    for (int i = 0; i < 16; ++i) {
+      zv[i] = zn[i];
+      const uint32_t ab = __float_as_uint(zv[i]) & 0x7fffffffu;
+      zmax_bits = ab > zmax_bits ? ab : zmax_bits;
+    }
     const int cn = c16 + 1 < n16 ? c16 + 1 : c16;
 #pragma unroll
     for (int i = 0; i < 16; ++i) zn[i] = zrow[(int64_t)(16 * cn + i) * zst];
@@ -460,6 +527,14 @@ __global__ __launch_bounds__(256) void vqf_verify_kernel(VerifyArgs a) {
         for (int i = 0; i < 16; ++i) acc[s] = __builtin_fmaf(zv[i], e[i >> 2][i & 3], acc[s]);
       }
     }
+  }
+  if (!listed) {  // the first level sees every row of the batch
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const uint32_t o = (uint32_t)__shfl_xor((int)zmax_bits, off);
+      zmax_bits = o > zmax_bits ? o : zmax_bits;
+    }
+    if ((threadIdx.x & 63) == 0 && zmax_bits) atomicMax(reinterpret_cast<unsigned int*>(&a.control[VQ_CTL_ZMAX]), zmax_bits);
   }
   const float z2 = pe + po;
   if (!(z2 <= VQ_NORM_LIMIT) || z2 < FQ_TINY_NORM) exact_row = true;
@@ -489,7 +564,7 @@ __global__ __launch_bounds__(256) void vqf_verify_kernel(VerifyArgs a) {
 template <int D, bool NCHW, int R>
 int launch_filter(const FilterArgs& a, hipStream_t s) {
   constexpr int STAGE_B = FQ_STAGE_TILES * (D / 16 + 1) * 1024;
-  const size_t lds_bytes = 2 * STAGE_B;
+  const size_t lds_bytes = 2 * STAGE_B + D * 4;
   auto kern = vqf_filter_kernel<D, NCHW, R>;
   static bool attr_done[64] = {};
   int dev = 0;
@@ -529,7 +604,8 @@ extern "C" {
 
 size_t vq_filter_image_bytes(int K, int D) {
   if (!vq_filter_supported(K, D)) return 256;
-  return (size_t)fq_tiles(K) * fq_steps(D) * 1024 + 256 + (size_t)fq_tiles(K) * 32 * 16;  // image, header, per-code terms
+  // image, header, per-code terms (8 floats), codebook mean and its partial sums
+  return (size_t)fq_tiles(K) * fq_steps(D) * 1024 + 256 + (size_t)fq_tiles(K) * 32 * 32 + (size_t)D * 4 * (1 + FQ_MEAN_PARTS);
 }
 
 
@@ -541,17 +617,22 @@ int vq_filter_prep(const float* E, const float* e2, int K, int D, void* fimage, 
   u32x4* image = static_cast<u32x4*>(fimage);
   uint32_t* hdr = reinterpret_cast<uint32_t*>(static_cast<char*>(fimage) + (size_t)tiles * fq_steps(D) * 1024);
   f32x4* aux = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(hdr) + 256);
+  float* mu = reinterpret_cast<float*>(reinterpret_cast<char*>(aux) + (size_t)tiles * 32 * 32);
   VQ_CHECK_HIP(hipMemsetAsync(hdr, 0, 256, s));
+  float* mu_partial = mu + D;
+  hipLaunchKernelGGL(vqf_mean_partial_kernel, dim3((D + 63) / 64, FQ_MEAN_PARTS), dim3(256), 0, s, E, K, D, mu_partial);
+  hipLaunchKernelGGL(vqf_mean_final_kernel, dim3((D + 255) / 256), dim3(256), 0, s, (const float*)mu_partial, K, D, mu);
   switch (D) {
-    case 64: hipLaunchKernelGGL(vqf_prep_kernel<64>, dim3(tiles), dim3(64), 0, s, E, e2, K, image, hdr, aux); break;
-    case 128: hipLaunchKernelGGL(vqf_prep_kernel<128>, dim3(tiles), dim3(64), 0, s, E, e2, K, image, hdr, aux); break;
-    default: hipLaunchKernelGGL(vqf_prep_kernel<256>, dim3(tiles), dim3(64), 0, s, E, e2, K, image, hdr, aux); break;
+    case 64: hipLaunchKernelGGL(vqf_prep_kernel<64>, dim3(tiles), dim3(64), 0, s, E, e2, K, mu, image, hdr, aux); break;
+    case 128: hipLaunchKernelGGL(vqf_prep_kernel<128>, dim3(tiles), dim3(64), 0, s, E, e2, K, mu, image, hdr, aux); break;
+    default: hipLaunchKernelGGL(vqf_prep_kernel<256>, dim3(tiles), dim3(64), 0, s, E, e2, K, mu, image, hdr, aux); break;
   }
   return vq_hip_status(hipGetLastError());
 }
 
-// Work buffer: [keys of pass 1: N x 32][row terms: N x 16][list A: N x 4][keys of pass 2: N x 64][row terms: N x 16][list B: N x 4]
-size_t vq_filter_work_bytes(int64_t N) { return N > 0 ? (size_t)N * 136 : 256; }
+// Work buffer: [keys of pass 1: N x 32][row terms: N x 32][list A: N x 4][keys of pass 2: N x 64][row terms: N x 32][list B: N x 4]
+// (regions laid out for N rounded up to a multiple of 4, which keeps each 16-byte aligned)
+size_t vq_filter_work_bytes(int64_t N) { return N > 0 ? (size_t)((N + 3) & ~(int64_t)3) * 168 : 256; }
 
 // Internal: filter + verify, two levels.  Settled rows get idx / dmin; rows for the exact kernel
 // are appended to nf_rows (control[VQ_CTL_NF_COUNT]); rows that overflowed both levels are left
@@ -563,15 +644,17 @@ int vq_filter_verify_launch(const float* z, int nchw, int64_t N, int D, int64_t 
   hipStream_t s = (hipStream_t)stream;
   const int tiles = fq_tiles(K);
   char* w = static_cast<char*>(work);
-  int32_t* listA = reinterpret_cast<int32_t*>(w + (size_t)N * 48);
-  int32_t* listB = reinterpret_cast<int32_t*>(w + (size_t)N * 132);
+  const size_t NP = (size_t)((N + 3) & ~(int64_t)3);   // region stride: keeps every region 16-byte aligned
+  int32_t* listA = reinterpret_cast<int32_t*>(w + NP * 64);
+  int32_t* listB = reinterpret_cast<int32_t*>(w + NP * 164);
   *hard_rows_out = listB;
   FilterArgs f{};
   f.z = z; f.image = static_cast<const u32x4*>(fimage);
   f.hdr = reinterpret_cast<const uint32_t*>(static_cast<const char*>(fimage) + (size_t)tiles * fq_steps(D) * 1024);
+  f.mu = reinterpret_cast<const float*>(reinterpret_cast<const char*>(f.hdr) + 256 + (size_t)tiles * 32 * 32);
   f.N = N; f.HW = nchw ? HW : 1; f.nstages = tiles / FQ_STAGE_TILES;
   f.cand = reinterpret_cast<u32x4*>(w);
-  f.rowaux = reinterpret_cast<f32x4*>(w + (size_t)N * 32);
+  f.rowaux = reinterpret_cast<f32x4*>(w + NP * 32);
   f.control = control;
   int rc = dispatch_filter<4>(f, D, nchw != 0, s);
   if (rc != VQ_OK) return rc;
@@ -583,8 +666,8 @@ int vq_filter_verify_launch(const float* z, int nchw, int64_t N, int D, int64_t 
   rc = launch_verify<4>(v, nchw != 0, s);
   if (rc != VQ_OK) return rc;
   // second level over list A: 8 keys per lane
-  f.cand = reinterpret_cast<u32x4*>(w + (size_t)N * 52);
-  f.rowaux = reinterpret_cast<f32x4*>(w + (size_t)N * 116);
+  f.cand = reinterpret_cast<u32x4*>(w + NP * 68);
+  f.rowaux = reinterpret_cast<f32x4*>(w + NP * 132);
   f.row_list = listA; f.count_word = VQ_CTL_OVF_COUNT;
   rc = dispatch_filter<8>(f, D, nchw != 0, s);
   if (rc != VQ_OK) return rc;
