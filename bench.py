@@ -118,6 +118,8 @@ def main() -> None:
     ap.add_argument("--rows", type=int, default=4 * 1024 * 1024, help="latent vectors per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-filtered", action="store_true", help="skip the extra timing of the filtered search")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only "
+                                                      "to rehearse the multi-rank path on a box with fewer GPUs)")
     ap.add_argument("--codebook", choices=["normal", "ref-init"], default="normal",
                     help="normal: N(0,1) rows (high utilisation, the headline case); ref-init: the reference's "
                          "U(-1/K, 1/K) initialisation, which collapses onto a few codes (skewed EMA scatter)")
@@ -129,6 +131,8 @@ def main() -> None:
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if args.backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())     # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -139,7 +143,10 @@ def main() -> None:
     stats_reduce = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
         stats_reduce = make_stats_reduce()
 
     rows = args.rows // (H * W) * (H * W)
