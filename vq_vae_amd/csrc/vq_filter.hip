@@ -264,12 +264,14 @@ __global__ __launch_bounds__(512, 2) void vqf_filter_kernel(FilterArgs a) {
   for (int i = 0; i < 5; ++i) hmax[i] = __uint_as_float(a.hdr[i]);
 
   u32x4 zb[2][FS];
+  uint32_t zmax_bits = 0;  // max |z| (bit pattern), for the EMA scatter's fixed-point scale
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) {
     int64_t n = row0 + ct * 32 + j;
     if (n >= nrows) n = nrows - 1;
     if (listed) n = a.row_list[n];
     float zt2 = 0.0f, dz2 = 0.0f, zu2 = 0.0f;
+    uint32_t am = 0;
 #pragma unroll
     for (int s = 0; s < ZS; ++s) {
       // keep at most four steps' loads in flight: more would not fit the register file
@@ -291,6 +293,8 @@ __global__ __launch_bounds__(512, 2) void vqf_filter_kernel(FilterArgs a) {
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
+        const uint32_t ab = __float_as_uint(v[i]) & 0x7fffffffu;
+        am = ab > am ? ab : am;
         zu2 = __builtin_fmaf(v[i], v[i], zu2);
         v[i] = v[i] - mc[i];                               // centred
       }
@@ -305,7 +309,11 @@ __global__ __launch_bounds__(512, 2) void vqf_filter_kernel(FilterArgs a) {
         dz2 = __builtin_fmaf(r0, r0, dz2);
         dz2 = __builtin_fmaf(r1, r1, dz2);
       }
+      // the running maximum is pinned here: left to itself the compiler defers the whole max
+      // reduction to the end of the loop and keeps (spills) every raw value until then
+      asm volatile("" : "+v"(am));
     }
+    zmax_bits = am > zmax_bits ? am : zmax_bits;
     zt2 += __shfl_xor(zt2, 32);
     dz2 += __shfl_xor(dz2, 32);
     zu2 += __shfl_xor(zu2, 32);
@@ -322,7 +330,10 @@ __global__ __launch_bounds__(512, 2) void vqf_filter_kernel(FilterArgs a) {
     const float c5 = bf16_up(go * 1.0001f);                                 // times ||e_k||^2
     // largest code-dependent part over the codebook
     const float wmax = (c1 * hmax[0] + c2 * hmax[1] + c3 * hmax[2] + c4 * hmax[3] + c5 * hmax[4]) * 1.0001f;
-    const float cst = (gf * (1.01f * zc * zc + 3.1f * wmax) + go * zn * zn * 1.0001f + 1.0e-30f + nz * 1.0e-35f) * 1.001f;
+    float cst = (gf * (1.01f * zc * zc + 3.1f * wmax) + go * zn * zn * 1.0001f + 1.0e-30f + nz * 1.0e-35f) * 1.001f;
+    // rows that are not finite, or so small that bf16 would flush them: a NaN constant sends them
+    // to the exact kernel (the verification tests its threshold for NaN)
+    if (!(zu2 <= VQ_NORM_LIMIT) || zu2 < FQ_TINY_NORM) cst = __builtin_nanf("");
     {
       // written now rather than after the sweep: 16 registers less to carry through it
       const int64_t pos = row0 + ct * 32 + j;
@@ -343,6 +354,15 @@ __global__ __launch_bounds__(512, 2) void vqf_filter_kernel(FilterArgs a) {
     }
     zb[ct][ZS] = extra;
   }
+  if (!listed) {  // the first level sees every row of the batch
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const uint32_t o = (uint32_t)__shfl_xor((int)zmax_bits, off);
+      zmax_bits = o > zmax_bits ? o : zmax_bits;
+    }
+    if (lane == 0 && zmax_bits) atomicMax(reinterpret_cast<unsigned int*>(&a.control[VQ_CTL_ZMAX]), zmax_bits);
+  }
+
   uint32_t maskv = FQ_KEY_MASK;
   asm volatile("" : "+v"(maskv));
   float m[2][R];
@@ -470,9 +490,21 @@ __global__ __launch_bounds__(256) void vqf_verify_kernel(VerifyArgs a) {
     if (__uint_as_float(kh[g][R - 1] & FQ_KEY_MASK) <= thr) overflow = true;  // the list may be incomplete
   if (!ok[0]) exact_row = true;
   if (exact_row || overflow) {
+    // -2: the exact kernel's row, -1: next level's row (the gather skips both)
+    if (a.idx64) a.idx64[n] = exact_row ? -2 : -1;
+    a.idx32[n] = exact_row ? -2 : -1;
+    if (exact_row) a.nf_rows[atomicAdd(&a.control[VQ_CTL_NF_COUNT], 1)] = (int32_t)n;
+    else a.ovf_rows[atomicAdd(&a.control[a.ovf_word], 1)] = (int32_t)n;
+    return;
+  }
+  bool several = false;
 #pragma unroll
-    for (int s = 0; s < SL; ++s) { ok[s] = false; code[s] = 0; }
-    ok[0] = true;  // keeps the row's z pass (needed for the norm test) on a valid address
+  for (int s = 1; s < SL; ++s) several = several || ok[s];
+  if (!several && a.dmin == nullptr) {
+    // a single candidate is the argmin; without a distance to report the row needs no arithmetic
+    if (a.idx64) a.idx64[n] = (int64_t)code[0] + a.code_base;
+    a.idx32[n] = (int32_t)(code[0] + a.code_base);
+    return;
   }
 
   float acc[SL];
@@ -485,23 +517,18 @@ __global__ __launch_bounds__(256) void vqf_verify_kernel(VerifyArgs a) {
   else { zrow = a.z + n * a.D; zst = 1; }
   const f32x4* erow[SL];
 #pragma unroll
-  for (int s = 0; s < SL; ++s) erow[s] = reinterpret_cast<const f32x4*>(a.E + (size_t)code[s] * a.D);
+  for (int s = 0; s < SL; ++s) erow[s] = reinterpret_cast<const f32x4*>(a.E + (size_t)(ok[s] ? code[s] : code[0]) * a.D);
   // 16 channels per step: a lane's four 16-byte reads of a code row are issued back to back, so
   // the 64-byte sector fetched by the first serves the other three (rows of different lanes share
   // nothing, so a sector used once would cost four times the traffic).
   const int n16 = a.D / 16;
-  uint32_t zmax_bits = 0;  // max |z| (bit pattern) of this row, for the EMA scatter's fixed-point scale
   float zn[16];  // the next step's latent values are in flight while this step computes
 #pragma unroll
   for (int i = 0; i < 16; ++i) zn[i] = zrow[(int64_t)i * zst];
   for (int c16 = 0; c16 < n16; ++c16) {
     float zv[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      zv[i] = zn[i];
-      const uint32_t ab = __float_as_uint(zv[i]) & 0x7fffffffu;
-      zmax_bits = ab > zmax_bits ? ab : zmax_bits;
-    }
+    for (int i = 0; i < 16; ++i) zv[i] = zn[i];
     const int cn = c16 + 1 < n16 ? c16 + 1 : c16;
 #pragma unroll
     for (int i = 0; i < 16; ++i) zn[i] = zrow[(int64_t)(16 * cn + i) * zst];
@@ -528,32 +555,22 @@ __global__ __launch_bounds__(256) void vqf_verify_kernel(VerifyArgs a) {
       }
     }
   }
-  if (!listed) {  // the first level sees every row of the batch
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const uint32_t o = (uint32_t)__shfl_xor((int)zmax_bits, off);
-      zmax_bits = o > zmax_bits ? o : zmax_bits;
-    }
-    if ((threadIdx.x & 63) == 0 && zmax_bits) atomicMax(reinterpret_cast<unsigned int*>(&a.control[VQ_CTL_ZMAX]), zmax_bits);
-  }
   const float z2 = pe + po;
-  if (!(z2 <= VQ_NORM_LIMIT) || z2 < FQ_TINY_NORM) exact_row = true;
+  if (!(z2 <= VQ_NORM_LIMIT) || z2 < FQ_TINY_NORM) exact_row = true;   // (the filter flags these rows already)
   float best = __builtin_inff();
   int bi = 0x7fffffff;
 #pragma unroll
   for (int s = 0; s < SL; ++s) {
-    float d = __builtin_fmaf(-2.0f, acc[s], z2 + a.e2[code[s]]);
+    float d = __builtin_fmaf(-2.0f, acc[s], z2 + a.e2[ok[s] ? code[s] : code[0]]);   // unused slots may hold any code
     if (a.T != 1.0f) d = d / a.T;
     const bool take = ok[s] && (d < best || (d == best && code[s] < bi));
     best = take ? d : best;
     bi = take ? code[s] : bi;
   }
-  if (exact_row || overflow) {
-    // -2: the exact kernel's row, -1: next level's row (the gather skips both)
-    if (a.idx64) a.idx64[n] = exact_row ? -2 : -1;
-    a.idx32[n] = exact_row ? -2 : -1;
-    if (exact_row) a.nf_rows[atomicAdd(&a.control[VQ_CTL_NF_COUNT], 1)] = (int32_t)n;
-    else a.ovf_rows[atomicAdd(&a.control[a.ovf_word], 1)] = (int32_t)n;
+  if (exact_row) {
+    if (a.idx64) a.idx64[n] = -2;
+    a.idx32[n] = -2;
+    a.nf_rows[atomicAdd(&a.control[VQ_CTL_NF_COUNT], 1)] = (int32_t)n;
   } else {
     if (a.idx64) a.idx64[n] = (int64_t)bi + a.code_base;
     a.idx32[n] = (int32_t)(bi + a.code_base);
