@@ -6,7 +6,7 @@
 One step = one training forward of the quantizer over one batch of synthetic latents already
 resident in HBM: codebook prep, MFMA nearest-code search fused with gather / straight-through /
 loss, code histogram, EMA embedding sums, scalars, EMA cluster + codebook update (and, for
-N > 1, the RCCL all-reduce of the EMA statistics).  Workload = BASELINE config 2: 4 Mi latent
+N > 1, the RCCL all-reduce of the EMA statistics).  Workload = benchmark configuration 2: 4 Mi latent
 vectors per GPU presented as (4096, 256, 32, 32) NCHW.  N > 1 is launched by
 torch.distributed.run, one rank per GPU, rows sharded data-parallel (weak scaling).
 

@@ -140,7 +140,7 @@ def g4():
 
 
 def g6():
-    """Full BASELINE config 1 (K=512, D=64, batch 16 of 16x16 latents): indices stored whole,
+    """Full benchmark configuration 1 (K=512, D=64, batch 16 of 16x16 latents): indices stored whole,
     float outputs as float64 checksums; inputs are regenerated from their seeds."""
     K, D = 512, 64
     z = gauss(601, (16, D, 16, 16))

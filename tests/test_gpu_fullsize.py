@@ -1,4 +1,4 @@
-"""BASELINE config 2 at full size (K=8192, D=256, 4 Mi latent vectors) through size-independent
+"""benchmark configuration 2 at full size (K=8192, D=256, 4 Mi latent vectors) through size-independent
 properties, plus an oracle spot check on a random sample of rows."""
 import numpy as np
 import pytest

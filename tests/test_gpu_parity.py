@@ -41,7 +41,7 @@ def _bits(a):
 
 CASES = [
     # (K, D, z shape) -- NCHW unless 2-D
-    (512, 64, (16, 64, 16, 16)),        # BASELINE config 1
+    (512, 64, (16, 64, 16, 16)),        # benchmark configuration 1
     (8192, 256, (2, 256, 32, 32)),      # headline codebook shape, 2048 rows
     (64, 256, (1, 256, 8, 8)),          # improved_vq_config: K=64
     (100, 32, (3, 32, 5, 7)),           # K not a multiple of 64, HW=35 unaligned, rows % 256 != 0
@@ -249,7 +249,7 @@ def test_eval_step_leaves_state_alone(dev, ops):
 
 
 def test_golden_config1_on_gpu(dev, ops):
-    """BASELINE config 1 against the reference's own outputs (golden vector g6)."""
+    """benchmark configuration 1 against the reference's own outputs (golden vector g6)."""
     g = np.load(os.path.join(GOLDEN, "g6_config1.npz"))
     K, D = 512, 64
     z = gauss(int(g["z_seed"]), (16, D, 16, 16))

@@ -152,7 +152,7 @@ def test_headline_codebook_shape():
 
 def test_dense_port_matches_golden():
     """The dense one-hot torch formulation (the benchmark's CPU baseline) reproduces the
-    reference's outputs on golden vector g6 (BASELINE config 1)."""
+    reference's outputs on golden vector g6 (benchmark configuration 1)."""
     import torch
     from oracle.dense_port import dense_forward, new_state
     g = load("g6_config1.npz")
