@@ -257,3 +257,17 @@ def test_graphed_step_equals_eager(dev):
     print(f"K=512 D=64 N=4096 training step: eager {t_eager * 1e6:.0f} us, graph replay {t_graph * 1e6:.0f} us")
     with pytest.raises(RuntimeError):
         g(torch.zeros(2, D, 4, 4, device=dev))
+
+
+def test_last_step_counters_report_nonfinite_rows(dev):
+    K, D = 256, 32
+    m = make(K, D, 3.0, 0.95, gauss(70, (K, D)), dev)
+    m.eval()
+    z = gauss(71, (2, D, 8, 8))
+    m(torch.from_numpy(z).to(dev))
+    assert m.last_step_counters()["nonfinite_rows"] == 0
+    z[0, :, 1, 1] = np.nan
+    z[1, 2, 3, 3] = np.inf
+    m(torch.from_numpy(z).to(dev))
+    c = m.last_step_counters()
+    assert c["nonfinite_rows"] == 2 and not c["codebook_not_finite"]

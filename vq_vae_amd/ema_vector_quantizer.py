@@ -214,6 +214,18 @@ class EMAVectorQuantizer(nn.Module):
             "total_usage": v[4],
         }
 
+    def last_step_counters(self) -> dict:
+        """Counters of the most recent forward (one small device-to-host copy, i.e. a sync): rows that
+        were not finite and went through the exact kernel -- the reference neither masks nor
+        reports them (a NaN latent wins the argmin by torch's rule and is scattered into ema_w);
+        this module keeps that behaviour and makes it visible -- and, for the filtered search, the
+        rows its first and second pass left open."""
+        if self._ws is None or "control" not in self._ws._bufs:
+            return {"nonfinite_rows": 0, "codebook_not_finite": False, "filter_open_rows": 0, "filter_hard_rows": 0}
+        c = self._ws._bufs["control"][:64].view(torch.int32)[:8].cpu().tolist()
+        return {"nonfinite_rows": int(c[0]), "codebook_not_finite": bool(c[1]), "filter_open_rows": int(c[4]),
+                "filter_hard_rows": int(c[5])}
+
     # ------------------------------------------------------------------ maintenance
     # These run a few times per training run on K-sized tensors.  They keep the reference's
     # semantics; the per-code Python loops become batched tensor ops, so the random draws come
