@@ -248,7 +248,8 @@ int vq_pack_dist_index(const float* dmin, const int64_t* idx64, int64_t N, int64
 int vq_unpack_dist_index(const int64_t* packed, int64_t N, float* dmin, int64_t* idx64, int32_t* idx32,
                          void* stream);
 /* acc[n] = min(acc[n], other[n]) over packed keys: merges the winners of two codebook-row ranges
- * on one device (what the MIN all-reduce does across devices). */
+ * on one device (what the MIN all-reduce does across devices).  ref: the argmin of
+ * vqvae/ema_vector_quantizer.py:53 taken over row ranges of the codebook. */
 int vq_packed_min(int64_t* acc, const int64_t* other, int64_t N, void* stream);
 
 #ifdef __cplusplus

@@ -244,7 +244,7 @@ int vq_unpack_dist_index(const int64_t* packed, int64_t N, float* dmin, int64_t*
   return vq_hip_status(hipGetLastError());
 }
 
-int vq_version(void) { return 100; }
+int vq_version(void) { return 110; }
 
 const char* vq_status_string(int status) {
   if (status == VQ_OK) return "ok";
