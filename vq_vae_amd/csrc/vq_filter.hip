@@ -252,12 +252,13 @@ __global__ __launch_bounds__(512, 2) void vqf_filter_kernel(FilterArgs a) {
   }
   if ((int64_t)blockIdx.x * FQ_WG_ROWS >= nrows) return;  // list mode: the grid covers the worst case
 
-  fq_stage_copy<D>(a.image, 0, flds, wave, lane);
-
-  // the codebook mean, through LDS (behind the two stage buffers)
+  // the codebook mean, through LDS (behind the two stage buffers); the barrier comes before the
+  // first DMA is issued, so that it does not wait for that copy
   float* mus = reinterpret_cast<float*>(flds + 2 * STAGE_B);
   if (threadIdx.x < D) mus[threadIdx.x] = a.mu[threadIdx.x];
   __syncthreads();
+
+  fq_stage_copy<D>(a.image, 0, flds, wave, lane);   // lands while z is being loaded
 
   float hmax[5];
 #pragma unroll
