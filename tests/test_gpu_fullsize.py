@@ -55,3 +55,13 @@ def test_full_size_properties():
     E2 = E0.clone(); w2 = torch.zeros_like(ema_w); c2 = torch.zeros_like(cs); u2 = torch.zeros_like(usage)
     ops.quantize_step(z, E2, w2, c2, u2, beta=3.0, decay=0.95, epsilon=1e-5, temperature=1.0, training=True, ws=ws)
     assert torch.equal(E2, E) and torch.equal(w2, ema_w) and torch.equal(c2, cs)
+    # the filtered search at full size: the same step, bit for bit (loss sums to 1e-6: other partial order)
+    E3 = E0.clone(); w3 = torch.zeros_like(ema_w); c3 = torch.zeros_like(cs); u3 = torch.zeros_like(usage)
+    outf = ops.quantize_step(z, E3, w3, c3, u3, beta=3.0, decay=0.95, epsilon=1e-5, temperature=1.0, training=True,
+                             ws=ws, want_dmin=True, filtered=True)
+    torch.cuda.synchronize()
+    assert torch.equal(outf.indices, idx) and torch.equal(outf.quantized, q)
+    assert torch.equal(outf.dmin.view(torch.int32), out.dmin.view(torch.int32))
+    assert torch.equal(E3, E) and torch.equal(w3, ema_w) and torch.equal(c3, cs) and torch.equal(u3, usage)
+    assert abs(outf.loss.item() - out.loss.item()) <= 1e-6 * abs(out.loss.item())
+    assert torch.equal(outf.perplexity, out.perplexity)
