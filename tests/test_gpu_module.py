@@ -271,3 +271,26 @@ def test_last_step_counters_report_nonfinite_rows(dev):
     m(torch.from_numpy(z).to(dev))
     c = m.last_step_counters()
     assert c["nonfinite_rows"] == 2 and not c["codebook_not_finite"]
+
+
+def test_channels_last_input_is_consumed_without_copy(dev):
+    """A channels_last (NHWC in memory) input gives the same results as the NCHW tensor, the
+    quantized output comes back in channels_last, and gradients flow."""
+    K, D = 256, 64
+    E = gauss(80, (K, D)) * np.float32(0.5)
+    z = torch.from_numpy(gauss(81, (4, D, 16, 16))).to(dev)
+    zl = z.contiguous(memory_format=torch.channels_last)
+    assert not zl.is_contiguous()
+    ref = make(K, D, 3.0, 0.95, E, dev); ref.train()
+    cl = make(K, D, 3.0, 0.95, E, dev); cl.train()
+    a = z.clone().requires_grad_(True)
+    b = zl.clone(memory_format=torch.preserve_format).requires_grad_(True)
+    q0, l0, (p0, i0, _) = ref(a)
+    q1, l1, (p1, i1, _) = cl(b)
+    assert torch.equal(i0, i1) and torch.equal(q0, q1) and q1.is_contiguous(memory_format=torch.channels_last)
+    assert abs(l0.item() - l1.item()) <= 1e-6 * abs(l0.item()) and torch.equal(p0, p1)
+    for k, v in ref.state_dict().items():
+        assert rel_err(cl.state_dict()[k].cpu().numpy(), v.cpu().numpy()) <= 1e-6, k
+    (q0.sum() * 0.5 + l0).backward()
+    (q1.sum() * 0.5 + l1).backward()
+    assert rel_err(b.grad.cpu().numpy(), a.grad.cpu().numpy()) <= 1e-6

@@ -182,8 +182,8 @@ class EMAVectorQuantizer(nn.Module):
         z = inputs
         if z.dtype != torch.float32:
             z = z.float()          # the search always runs in fp32, also under autocast
-        if not z.is_contiguous():
-            z = z.contiguous()
+        if not z.is_contiguous() and not z.is_contiguous(memory_format=torch.channels_last):
+            z = z.contiguous()     # channels_last is consumed as it is: in memory it is the (N, D) matrix
         quantized, loss, perplexity, idx = _QuantizeFn.apply(z, self, float(temperature))
         n = idx.numel()
         encoding_indices = idx.view(n, 1)

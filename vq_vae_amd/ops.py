@@ -38,6 +38,20 @@ def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _rows_view(z: torch.Tensor):
+    """A channels_last (B, D, H, W) tensor is, in memory, the row-major (N, D) matrix of its latent
+    vectors.  Returns that 2-D view (no copy) and the function that gives an (N, D) result z's
+    shape and memory format back -- or (None, None) for every other input.  This is what spares a
+    channels_last pipeline the permute + contiguous copy of vqvae/ema_vector_quantizer.py:35."""
+    if (z.dim() == 4 and z.is_cuda and not z.is_contiguous()
+            and z.is_contiguous(memory_format=torch.channels_last)):
+        B, C, H, W = z.shape
+        rows = z.permute(0, 2, 3, 1).reshape(B * H * W, C)
+        if rows.data_ptr() == z.data_ptr():          # a view, as expected
+            return rows, (lambda t: t.view(B, H, W, C).permute(0, 3, 1, 2))
+    return None, None
+
+
 def ema_scalars(K: int, decay: float, epsilon: float):
     """The four fp32 constants of the EMA update, rounded as the reference's Python expressions
     round when they meet an fp32 tensor (vqvae/ema_vector_quantizer.py:71-79)."""
@@ -151,6 +165,16 @@ def search(z: torch.Tensor, E: torch.Tensor, ws: Workspace, temperature: float =
     Returns dict(indices int64 [N], idx32, dmin|None, quantized|None, loss_partial|None, n_partial).
     """
     lib = _lib.load()
+    if z.dtype != torch.float32:
+        z = z.float()
+    rows, back = _rows_view(z)
+    if rows is not None and z.shape[1] == E.shape[1]:
+        r = search(rows, E, ws, temperature=temperature, code_base=code_base, want_quantized=want_quantized,
+                   want_dmin=want_dmin, exact=exact, prepared=prepared, events=events, allow_split=allow_split,
+                   filtered=filtered)
+        if r["quantized"] is not None:
+            r["quantized"] = back(r["quantized"])
+        return r
     z = _f32c(z, "latents")
     E = _f32c(E, "codebook")
     K, D = E.shape
@@ -268,9 +292,22 @@ def ema_update(counts, slabs: torch.Tensor, usage, cluster_size, ema_w, E, decay
 
 
 def backward(grad_q, grad_loss, z, q_st, coef: float) -> torch.Tensor:
+    """grad_z = grad_q + grad_loss * coef * (z - q_st), elementwise over the storage: all operands
+    are brought to z's memory format first (channels_last stays channels_last)."""
     lib = _lib.load()
+    channels_last = (z.dim() == 4 and not z.is_contiguous() and z.is_contiguous(memory_format=torch.channels_last))
+    fmt = torch.channels_last if channels_last else torch.contiguous_format
+
+    def same(t, name):
+        _require_cuda(t, name)
+        if t.dtype != torch.float32:
+            t = t.float()
+        return t.contiguous(memory_format=fmt) if t.dim() == 4 else t.contiguous()
+
+    z = same(z, "latents")
+    q_st = same(q_st, "quantized")
     grad_z = torch.empty_like(z)
-    gq = None if grad_q is None else _f32c(grad_q, "grad_quantized")
+    gq = None if grad_q is None else same(grad_q, "grad_quantized")
     gl = None if grad_loss is None else _f32c(grad_loss, "grad_loss")
     check(lib.vq_backward(_ptr(gq), _ptr(gl), _ptr(z), _ptr(q_st), z.numel(), float(coef), _ptr(grad_z),
                           _stream(z.device)), "vq_backward")
@@ -309,6 +346,12 @@ def onehot(idx64: torch.Tensor, K: int) -> torch.Tensor:
 def gather_st(z: torch.Tensor, E: torch.Tensor, idx64: torch.Tensor, ws: Workspace):
     """Standalone gather + straight-through + loss partials.  Returns (q_st, loss_partial, n_partial)."""
     lib = _lib.load()
+    if z.dtype != torch.float32:
+        z = z.float()
+    rows, back = _rows_view(z)
+    if rows is not None and z.shape[1] == E.shape[1]:
+        q, lp, n_partial = gather_st(rows, E, idx64, ws)
+        return back(q), lp, n_partial
     z = _f32c(z, "latents")
     E = _f32c(E, "codebook")
     K, D = E.shape
@@ -333,6 +376,16 @@ def quantize_step(z: torch.Tensor, E: torch.Tensor, ema_w, cluster_size, usage, 
     local-batch mean, as it would under DistributedDataParallel.
     """
     K, D = E.shape
+    if z.dtype != torch.float32:
+        z = z.float()
+    rows, back = _rows_view(z)
+    if rows is not None and z.shape[1] == D:
+        # channels_last input: the whole step runs on the (N, D) view, the output gets z's format back
+        out = quantize_step(rows, E, ema_w, cluster_size, usage, beta=beta, decay=decay, epsilon=epsilon,
+                            temperature=temperature, training=training, ws=ws, want_dmin=want_dmin,
+                            stats_reduce=stats_reduce, search_events=search_events, filtered=filtered)
+        out.quantized = back(out.quantized)
+        return out
     r = search(z, E, ws, temperature=temperature, want_quantized=True, want_dmin=want_dmin, events=search_events,
                filtered=filtered)
     N = r["N"]
