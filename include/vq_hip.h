@@ -48,7 +48,8 @@ int64_t vq_search_blocks(int64_t N);            /* workgroups of vq_search = los
 size_t vq_loss_partial_bytes(int64_t N);        /* floats: vq_search_blocks(N) + fix-up partials   */
 size_t vq_control_bytes(void);                  /* small block of control words                    */
 size_t vq_search_split_bytes(int64_t N, int K); /* scratch of the small-batch codebook split (0: unused)*/
-int vq_scatter_slabs(int64_t N, int K, int D);  /* number of partial-sum slabs vq_ema_scatter writes*/
+int vq_scatter_slabs(int64_t N, int K, int D);  /* number of partial-sum slabs vq_ema_scatter writes (NCHW)*/
+int vq_scatter_slabs_for(int64_t N, int K, int D, int layout, int64_t HW); /* the same for a given layout */
 
 /*
  * Codebook preparation.  ref: vqvae/ema_vector_quantizer.py:44 (sum(E**2, dim=1)).
@@ -142,7 +143,10 @@ int vq_code_histogram(const void* idx, int idx_is_64, int64_t M, int K, uint32_t
 /*
  * EMA embedding sums: slab[s][k][c] = sum of z[n][c] over the rows n of slab s with
  * idx32[n] == code_base + k.  ref: vqvae/ema_vector_quantizer.py:84 (encodings.t() @ flat_input).
- * Writes vq_scatter_slabs(N,K,D) slabs of K*D floats; their sum over s is dw.  The sums are
+ * Writes `nslab` slabs of K*D floats, nslab = vq_scatter_slabs_for(N, K, D, layout, HW) (0 stands for
+ * vq_scatter_slabs(N, K, D)); their sum over s is dw.  NCHW: a workgroup owns two channels and all
+ * codes; row-major (also what a channels_last tensor is in memory): a workgroup owns a range of
+ * codes with all channels and reads each matching row once, whole.  The sums are
  * accumulated in LDS in 64-bit fixed point scaled from max|z| (control word 3, written by
  * vq_search for the same z; pass zmax_valid = 0 to have it computed here), so they do not
  * depend on arrival order: bit-reproducible, each element rounded once at max|z| * 2^-40 or
@@ -151,7 +155,7 @@ int vq_code_histogram(const void* idx, int idx_is_64, int64_t M, int K, uint32_t
  * (codebook-row sharding: a rank accumulates only the rows its shard won).
  */
 int vq_ema_scatter(const float* z, int layout, int64_t N, int D, int64_t HW, const int32_t* idx32, int K,
-                   int64_t code_base, int zmax_valid, int32_t* control, float* slabs, void* stream);
+                   int64_t code_base, int zmax_valid, int32_t* control, float* slabs, int nslab, void* stream);
 
 /* dw[k][c] = sum_s slabs[s][k][c] in slab order (packs the data-parallel all-reduce buffer). */
 int vq_reduce_slabs(const float* slabs, int nslab, int K, int D, float* dw, void* stream);

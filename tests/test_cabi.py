@@ -60,7 +60,7 @@ def test_entry_points_reject_bad_arguments_without_a_gpu():
     assert lib.vq_search(None, 1, 128, 64, 64, None, None, None, 512, 1.0, 0, None, None, None, None, None, None,
                          None, None, None) == 1
     assert lib.vq_code_histogram(None, 0, 10, 512, None, 0, None, None) == 1
-    assert lib.vq_ema_scatter(None, 1, 128, 64, 64, None, 512, 0, 0, None, None, None) == 1
+    assert lib.vq_ema_scatter(None, 1, 128, 64, 64, None, 512, 0, 0, None, None, 0, None) == 1
 
 
 def test_module_interface_matches_reference():

@@ -43,8 +43,9 @@ SIGNATURES = {
     "vq_gather_st": (c_int, [c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                              c_void_p]),
     "vq_code_histogram": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "vq_scatter_slabs_for": (c_int, [c_int64, c_int, c_int, c_int, c_int64]),
     "vq_ema_scatter": (c_int, [c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_int, c_int64, c_int, c_void_p,
-                               c_void_p, c_void_p]),
+                               c_void_p, c_int, c_void_p]),
     "vq_reduce_slabs": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vq_step_scalars": (c_int, [c_void_p, c_int64, c_int64, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p,
                                 c_void_p, c_void_p]),

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void vq_hist_global_kernel(const IndexT* __res
 //
 // LDS float atomics (ds_add_f32) run at well under one lane per clock on gfx950, while the
 // integer ones (ds_add_u32/u64) run at full bank rate, so the sums are kept in 64-bit
-// fixed point: every value is scaled by 2^F (F chosen from max|z| and the slab's row count
+// fixed point: every value is scaled by 2^F (F chosen from max|z| and the batch's row count
 // so that no sum can overflow), rounded once to an integer, and added with ds_add_u64.
 // Integer addition commutes exactly, so the result is independent of the order in which
 // waves and lanes arrive -- bit-reproducible -- and its error (one rounding of at most
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(SCAT_THREADS) void vq_scatter_kernel(const float* _
   const int kr_len = (K - k0) < SCAT_KR ? (K - k0) : SCAT_KR;
   for (int i = threadIdx.x; i < 2 * kr_len; i += SCAT_THREADS) acc_i[i] = 0ull;
 
-  // fixed-point scale: max|z| < 2^e, at most 2^r rows per slab  =>  |sum| * 2^F < 2^62
+  // fixed-point scale: max|z| < 2^e, at most 2^r rows  =>  |sum| * 2^F < 2^62
   const uint32_t zmax_bits = (uint32_t)control[VQ_CTL_ZMAX];
   // 0 = unknown (or an all-zero batch): the float path is always valid
   const bool fixed = zmax_bits != 0 && zmax_bits < 0x7f800000u;
@@ -137,7 +137,9 @@ __global__ __launch_bounds__(SCAT_THREADS) void vq_scatter_kernel(const float* _
   if (fixed) {
     int e;
     (void)frexpf(__uint_as_float(zmax_bits), &e);  // zmax = m * 2^e, m in [0.5, 1)
-    const int r = 32 - __clz((unsigned)(rows_per_slab > 1 ? rows_per_slab - 1 : 1));
+    // (r from the batch's row count, not from the slab's: the scale, and with it every bit of a
+    // slab's sums, does not depend on the slab plan)
+    const int r = 32 - __clz((unsigned)(N > 1 ? N - 1 : 1));
     F = 62 - e - r;
   }
   const double scale = ldexp(1.0, F), inv_scale = ldexp(1.0, -F);
@@ -217,6 +219,122 @@ __global__ __launch_bounds__(SCAT_THREADS) void vq_scatter_kernel(const float* _
     dst[0] = s0;
     if (c0 + 1 < D) dst[1] = s1;
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// Row-major z ((N, D), which is also what a channels_last tensor is in memory), D % 4 == 0.
+// There a row's D values are contiguous, so the decomposition turns around: a workgroup owns a
+// range of srow_codes(D) codes with ALL channels in LDS (32 KiB, four workgroups per CU: the
+// kernel lives on memory latency, so occupancy is what counts) and one slab of rows.  Its waves
+// scan the slab's indices 256 rows at a time; a row whose code falls in the range is read whole
+// -- one coalesced float4 per lane -- and added to the code's LDS row by conflict-free ds_add_u64
+// (lane l owns channels 4l .. 4l+3).  Up to four matched rows are in flight per wave.  z is read
+// exactly once over all workgroups; the indices are re-read once per code range, from L2.
+// ---------------------------------------------------------------------------------------
+__host__ __device__ inline int srow_codes(int D) { return 4096 / D > 0 ? 4096 / D : 1; }   // x D x 8 B = 32 KiB
+
+__global__ __launch_bounds__(SCAT_THREADS) void vq_scatter_rows_kernel(const float* __restrict__ z, int N, int D,
+                                                                       const int32_t* __restrict__ idx32, int K,
+                                                                       int code_base, int rows_per_slab,
+                                                                       const int32_t* __restrict__ control,
+                                                                       float* __restrict__ slabs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long racc_i[];  // [codes][D] int64, or floats
+  float* racc_f = reinterpret_cast<float*>(racc_i);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int KR = srow_codes(D);
+  const int k0 = blockIdx.x * KR;
+  const int kr_len = (K - k0) < KR ? (K - k0) : KR;
+  const int slab = blockIdx.y;
+  for (int i = threadIdx.x; i < kr_len * D; i += SCAT_THREADS) racc_i[i] = 0ull;
+
+  const uint32_t zmax_bits = (uint32_t)control[VQ_CTL_ZMAX];
+  const bool fixed = zmax_bits != 0 && zmax_bits < 0x7f800000u;   // see vq_scatter_kernel
+  int F = 0;
+  if (fixed) {
+    int e;
+    (void)frexpf(__uint_as_float(zmax_bits), &e);
+    const int r = 32 - __clz((unsigned)(N > 1 ? N - 1 : 1));
+    F = 62 - e - r;
+  }
+  const double scale = ldexp(1.0, F), inv_scale = ldexp(1.0, -F);
+  __syncthreads();
+
+  const int n_begin = slab * rows_per_slab;
+  const int n_end = (N - n_begin) < rows_per_slab ? N : n_begin + rows_per_slab;
+  const int kbase = code_base + k0;
+  const int D4 = D >> 2;
+  for (int g0 = n_begin + wave * 256; g0 < n_end; g0 += 8 * 256) {
+    // this wave's 256 rows: four groups of 64, lane = row within the group
+    int kk[4];
+    uint64_t mask[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = g0 + 64 * q + lane;
+      kk[q] = n < n_end ? idx32[n] - kbase : -1;
+      mask[q] = __ballot((unsigned)kk[q] < (unsigned)kr_len);
+    }
+    // pop matched rows, up to four at a time
+    int q = 0;
+    while (q < 4) {
+      int rown[4], rowk[4];
+      int cnt = 0;
+      while (cnt < 4 && q < 4) {
+        if (mask[q] == 0) { ++q; continue; }
+        const int b = __builtin_ctzll(mask[q]);
+        mask[q] &= mask[q] - 1;
+        rown[cnt] = g0 + 64 * q + b;
+        rowk[cnt] = __builtin_amdgcn_readlane(kk[q], b);
+        ++cnt;
+      }
+      for (int c4 = lane; c4 < D4; c4 += 64) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (u < cnt) v[u] = reinterpret_cast<const f32x4*>(z + (size_t)rown[u] * D)[c4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (u < cnt) {
+            const int base = rowk[u] * D + 4 * c4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              if (fixed) atomicAdd(&racc_i[base + i], (unsigned long long)__double2ll_rn((double)v[u][i] * scale));
+              else atomicAdd(&racc_f[base + i], v[u][i]);
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // flush: slab[k0 + kk][:] , coalesced float4
+  float* out = slabs + ((size_t)slab * K + k0) * D;
+  for (int i = threadIdx.x; i < kr_len * D4; i += SCAT_THREADS) {
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      o[j] = fixed ? (float)((double)(long long)racc_i[4 * i + j] * inv_scale) : racc_f[4 * i + j];
+    reinterpret_cast<f32x4*>(out)[i] = o;
+  }
+}
+
+// slabs of the row-major kernel: enough workgroups to fill the chip, and enough slabs that a batch
+// whose rows all pick one code still spreads over many CUs
+ScatterPlan scatter_plan_rows(int64_t N, int K, int D) {
+  const int ranges = (K + srow_codes(D) - 1) / srow_codes(D);
+  int64_t want = (4096 + ranges - 1) / ranges;
+  if (want < 16) want = 16;
+  const int64_t maxslab = (N + SCAT_MIN_ROWS - 1) / SCAT_MIN_ROWS;
+  if (want > maxslab) want = maxslab;
+  if (want < 1) want = 1;
+  if (want > 64) want = 64;
+  int64_t rows = (N + want - 1) / want;
+  rows = (rows + 2047) / 2048 * 2048;      // a workgroup's eight waves take 2048 rows per round
+  return {(int)((N + rows - 1) / rows), rows};
+}
+
+bool scatter_rows_ok(int layout, int64_t HW, int D, const float* z) {
+  const bool rowmajor = layout == VQ_LAYOUT_ND || HW <= 1;
+  return rowmajor && (D % 4 == 0) && D <= 2048 && ((reinterpret_cast<uintptr_t>(z) & 15) == 0);
 }
 
 __global__ __launch_bounds__(256) void vq_reduce_slabs_kernel(const float* __restrict__ slabs, int nslab, int64_t KD,
@@ -437,6 +555,14 @@ int vq_scatter_slabs(int64_t N, int K, int D) {
   return scatter_plan(N, K, D).nslab;
 }
 
+int vq_scatter_slabs_for(int64_t N, int K, int D, int layout, int64_t HW) {
+  if (N <= 0 || K <= 0 || D <= 0) return 0;
+  // (a row-major z that turns out not to be 16-byte aligned takes the generic kernel, which writes
+  // fewer slabs and zero-fills the rest)
+  if (scatter_rows_ok(layout, HW, D, nullptr)) return scatter_plan_rows(N, K, D).nslab;
+  return scatter_plan(N, K, D).nslab;
+}
+
 int vq_code_histogram(const void* idx, int idx_is_64, int64_t M, int K, uint32_t* counts, int accumulate,
                       int32_t* control, void* stream) {
   if (!idx || !counts || M < 0 || K <= 0) return VQ_ERR_INVALID_ARG;
@@ -466,7 +592,7 @@ int vq_code_histogram(const void* idx, int idx_is_64, int64_t M, int K, uint32_t
 }
 
 int vq_ema_scatter(const float* z, int layout, int64_t N, int D, int64_t HW, const int32_t* idx32, int K,
-                   int64_t code_base, int zmax_valid, int32_t* control, float* slabs, void* stream) {
+                   int64_t code_base, int zmax_valid, int32_t* control, float* slabs, int nslab_given, void* stream) {
   if (!z || !idx32 || !slabs || !control || N <= 0 || K <= 0 || D <= 0) return VQ_ERR_INVALID_ARG;
   if (layout != VQ_LAYOUT_ND && layout != VQ_LAYOUT_NCHW) return VQ_ERR_INVALID_ARG;
   if (layout == VQ_LAYOUT_NCHW && (HW <= 0 || N % HW != 0)) return VQ_ERR_INVALID_ARG;
@@ -476,7 +602,20 @@ int vq_ema_scatter(const float* z, int layout, int64_t N, int D, int64_t HW, con
     int rc = vq_launch_absmax(z, N * D, control, s);
     if (rc != VQ_OK) return rc;
   }
+  if (scatter_rows_ok(layout, HW, D, z) && nslab_given != 0) {
+    const ScatterPlan rp = scatter_plan_rows(N, K, D);
+    if (rp.nslab == nslab_given) {
+      const size_t rlds = (size_t)srow_codes(D) * D * 8;
+      const dim3 rgrid((K + srow_codes(D) - 1) / srow_codes(D), rp.nslab);
+      hipLaunchKernelGGL(vq_scatter_rows_kernel, rgrid, dim3(SCAT_THREADS), rlds, s, z, (int)N, D, idx32, K,
+                         (int)code_base, (int)rp.rows_per_slab, control, slabs);
+      return vq_hip_status(hipGetLastError());
+    }
+  }
   const ScatterPlan p = scatter_plan(N, K, D);
+  if (nslab_given != 0 && nslab_given < p.nslab) return VQ_ERR_INVALID_ARG;
+  if (nslab_given > p.nslab)   // (a row-major z that is not 16-byte aligned: the slabs this kernel does not write are zero)
+    VQ_CHECK_HIP(hipMemsetAsync(slabs + (size_t)p.nslab * K * D, 0, (size_t)(nslab_given - p.nslab) * K * D * 4, s));
   const int kr = (K + SCAT_KR - 1) / SCAT_KR;
   const int kr_len = K < SCAT_KR ? K : SCAT_KR;
   const size_t lds = (size_t)2 * kr_len * 8;

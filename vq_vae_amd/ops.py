@@ -247,11 +247,11 @@ def embed_sums(z: torch.Tensor, idx32: torch.Tensor, K: int, ws: Workspace, code
     z = _f32c(z, "latents")
     D = z.shape[1]
     layout, N, HW = _shape_of(z, D)
-    nslab = lib.vq_scatter_slabs(N, K, D)
+    nslab = lib.vq_scatter_slabs_for(N, K, D, layout, HW)
     slabs = ws.get("slabs", nslab * K * D * 4, torch.float32)[: nslab * K * D].view(nslab, K, D)
     control = ws.get("control", lib.vq_control_bytes(), torch.int32)
     check(lib.vq_ema_scatter(_ptr(z), layout, N, D, HW, _ptr(idx32), K, code_base, 1 if zmax_valid else 0,
-                             _ptr(control), _ptr(slabs), _stream(z.device)), "vq_ema_scatter")
+                             _ptr(control), _ptr(slabs), nslab, _stream(z.device)), "vq_ema_scatter")
     return slabs, nslab
 
 
