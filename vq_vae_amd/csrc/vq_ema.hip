@@ -225,11 +225,11 @@ __global__ __launch_bounds__(SCAT_THREADS) void vq_scatter_kernel(const float* _
 // Row-major z ((N, D), which is also what a channels_last tensor is in memory), D % 4 == 0.
 // There a row's D values are contiguous, so the decomposition turns around: a workgroup owns a
 // range of srow_codes(D) codes with ALL channels in LDS (32 KiB, four workgroups per CU: the
-// kernel lives on memory latency, so occupancy is what counts) and one slab of rows.  Its waves
-// scan the slab's indices 256 rows at a time; a row whose code falls in the range is read whole
-// -- one coalesced float4 per lane -- and added to the code's LDS row by conflict-free ds_add_u64
-// (lane l owns channels 4l .. 4l+3).  Up to four matched rows are in flight per wave.  z is read
-// exactly once over all workgroups; the indices are re-read once per code range, from L2.
+// kernel lives on memory latency) and one slab of rows.  Its waves scan the slab's indices 512
+// rows at a time; a row whose code falls in the range is read whole -- one coalesced float4 per
+// lane -- and added to the code's LDS row by conflict-free ds_add_u64 (lane l owns channels
+// 4l .. 4l+3).  z is read exactly once over all workgroups; the indices are re-read once per code
+// range, from L2.
 // ---------------------------------------------------------------------------------------
 __host__ __device__ inline int srow_codes(int D) { return 4096 / D > 0 ? 4096 / D : 1; }   // x D x 8 B = 32 KiB
 
@@ -263,37 +263,28 @@ __global__ __launch_bounds__(SCAT_THREADS) void vq_scatter_rows_kernel(const flo
   const int n_end = (N - n_begin) < rows_per_slab ? N : n_begin + rows_per_slab;
   const int kbase = code_base + k0;
   const int D4 = D >> 2;
-  for (int g0 = n_begin + wave * 256; g0 < n_end; g0 += 8 * 256) {
-    // this wave's 256 rows: four groups of 64, lane = row within the group
-    int kk[4];
-    uint64_t mask[4];
+  // Matches are sparse (a range holds srow_codes of K codes), and a row fetched on the spot would
+  // cost the wave a full memory latency each.  So a wave first collects (row, code) pairs in a
+  // list of its own in LDS and drains it eight rows at a time, all eight loads in flight.
+  volatile int2* list = reinterpret_cast<volatile int2*>(racc_i + (size_t)KR * D) + wave * 128;
+  int cnt = 0;   // wave-uniform
+
+  auto drain = [&]() {
+    for (int e0 = 0; e0 < cnt; e0 += 8) {
+      int rown[8], rowk[8];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int n = g0 + 64 * q + lane;
-      kk[q] = n < n_end ? idx32[n] - kbase : -1;
-      mask[q] = __ballot((unsigned)kk[q] < (unsigned)kr_len);
-    }
-    // pop matched rows, up to four at a time
-    int q = 0;
-    while (q < 4) {
-      int rown[4], rowk[4];
-      int cnt = 0;
-      while (cnt < 4 && q < 4) {
-        if (mask[q] == 0) { ++q; continue; }
-        const int b = __builtin_ctzll(mask[q]);
-        mask[q] &= mask[q] - 1;
-        rown[cnt] = g0 + 64 * q + b;
-        rowk[cnt] = __builtin_amdgcn_readlane(kk[q], b);
-        ++cnt;
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u < cnt ? e0 + u : e0;
+        rown[u] = __builtin_amdgcn_readfirstlane(list[e].x);
+        rowk[u] = __builtin_amdgcn_readfirstlane(list[e].y);
       }
       for (int c4 = lane; c4 < D4; c4 += 64) {
-        f32x4 v[4];
+        f32x4 v[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (u < cnt) v[u] = reinterpret_cast<const f32x4*>(z + (size_t)rown[u] * D)[c4];
+        for (int u = 0; u < 8; ++u) v[u] = reinterpret_cast<const f32x4*>(z + (size_t)rown[u] * D)[c4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (u < cnt) {
+        for (int u = 0; u < 8; ++u) {
+          if (e0 + u < cnt) {
             const int base = rowk[u] * D + 4 * c4;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -304,7 +295,32 @@ __global__ __launch_bounds__(SCAT_THREADS) void vq_scatter_rows_kernel(const flo
         }
       }
     }
+    cnt = 0;
+  };
+
+  for (int g0 = n_begin + wave * 512; g0 < n_end; g0 += 8 * 512) {
+    int kk[8];   // this wave's 512 rows: eight groups of 64, lane = row within the group
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int n = g0 + 64 * q + lane;
+      kk[q] = n < n_end ? idx32[n] - kbase : -1;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const bool m = (unsigned)kk[q] < (unsigned)kr_len;
+      const uint64_t mask = __ballot(m);
+      if (mask != 0) {
+        if (m) {
+          const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+          list[pos].x = g0 + 64 * q + lane;
+          list[pos].y = kk[q];
+        }
+        cnt += __builtin_popcountll(mask);
+        if (cnt >= 64) drain();
+      }
+    }
   }
+  drain();
   __syncthreads();
   // flush: slab[k0 + kk][:] , coalesced float4
   float* out = slabs + ((size_t)slab * K + k0) * D;
@@ -328,7 +344,7 @@ ScatterPlan scatter_plan_rows(int64_t N, int K, int D) {
   if (want < 1) want = 1;
   if (want > 64) want = 64;
   int64_t rows = (N + want - 1) / want;
-  rows = (rows + 2047) / 2048 * 2048;      // a workgroup's eight waves take 2048 rows per round
+  rows = (rows + 4095) / 4096 * 4096;      // a workgroup's eight waves take 4096 rows per round
   return {(int)((N + rows - 1) / rows), rows};
 }
 
@@ -605,7 +621,7 @@ int vq_ema_scatter(const float* z, int layout, int64_t N, int D, int64_t HW, con
   if (scatter_rows_ok(layout, HW, D, z) && nslab_given != 0) {
     const ScatterPlan rp = scatter_plan_rows(N, K, D);
     if (rp.nslab == nslab_given) {
-      const size_t rlds = (size_t)srow_codes(D) * D * 8;
+      const size_t rlds = (size_t)srow_codes(D) * D * 8 + 8 * 128 * 8;   // sums + the waves' row lists
       const dim3 rgrid((K + srow_codes(D) - 1) / srow_codes(D), rp.nslab);
       hipLaunchKernelGGL(vq_scatter_rows_kernel, rgrid, dim3(SCAT_THREADS), rlds, s, z, (int)N, D, idx32, K,
                          (int)code_base, (int)rp.rows_per_slab, control, slabs);
