@@ -224,12 +224,12 @@ __global__ __launch_bounds__(SCAT_THREADS) void vq_scatter_kernel(const float* _
 // ---------------------------------------------------------------------------------------
 // Row-major z ((N, D), which is also what a channels_last tensor is in memory), D % 4 == 0.
 // There a row's D values are contiguous, so the decomposition turns around: a workgroup owns a
-// range of srow_codes(D) codes with ALL channels in LDS (32 KiB, four workgroups per CU: the
-// kernel lives on memory latency) and one slab of rows.  Its waves scan the slab's indices 512
-// rows at a time; a row whose code falls in the range is read whole -- one coalesced float4 per
-// lane -- and added to the code's LDS row by conflict-free ds_add_u64 (lane l owns channels
-// 4l .. 4l+3).  z is read exactly once over all workgroups; the indices are re-read once per code
-// range, from L2.
+// range of srow_codes(D) codes with ALL channels in LDS (32 KiB of sums + 8 KiB of row lists: the
+// kernel lives on memory latency, so several workgroups share a CU) and one slab of rows.  Its
+// waves scan the slab's indices 512 rows at a time and list the rows whose code falls in the
+// range; a listed row is read whole -- one coalesced float4 per lane -- and added to the code's
+// LDS row by conflict-free ds_add_u64 (lane l owns channels 4l .. 4l+3).  z is read exactly once
+// over all workgroups; the indices are re-read once per code range, from L2.
 // ---------------------------------------------------------------------------------------
 __host__ __device__ inline int srow_codes(int D) { return 4096 / D > 0 ? 4096 / D : 1; }   // x D x 8 B = 32 KiB
 
