@@ -197,6 +197,31 @@ int vq_backward(const float* grad_q, const float* grad_loss, const float* z, con
                 float coef, float* grad_z, void* stream);
 
 /*
+ * The quantizer followed by a 1x1 convolution.  ref: vqvae/custom_vqgan.py:51, :72 (post_quant_conv)
+ * applied at :95 to the output of the quantizer (:81); loss as vqvae/ema_vector_quantizer.py:92.
+ * Every quantized row is a codebook row, so the convolution of the N rows equals a gather from the
+ * convolved codebook  P = E W^T + b  (K x DP, computed by the caller with any GEMM):
+ *   out[n, :] = P[idx64[n], :]   in the layout of z (NCHW with DP channels, or (N, DP) rows)
+ *   loss_partial[w] = sum over the 256 rows of workgroup w of |E[idx64[n]] - z[n]|^2  (may be NULL)
+ * loss_partial gets vq_search_blocks(N) floats.  E and P 16-byte aligned.  Rows whose index is
+ * outside [0, K) are skipped, as in vq_gather_st.
+ */
+int vq_gather_project(const float* z, int layout, int64_t N, int D, int64_t HW, const float* E, int K,
+                      const int64_t* idx64, const float* P, int DP, float* out, float* loss_partial, void* stream);
+
+/*
+ * vq_backward with the quantized row read from a codebook instead of a stored N x D tensor:
+ *   grad_z[n, :] = grad_q[n, :] + grad_loss * coef * (z[n, :] - E[idx64[n], :])
+ * E is the codebook the forward searched (the caller keeps a copy across the EMA update, K x D
+ * floats instead of N x D).  ref: autograd of vqvae/ema_vector_quantizer.py:92 and :95.
+ * grad_q may be NULL; grad_loss is a device scalar (NULL = 0); a row whose index is outside [0, K)
+ * passes grad_q through.
+ */
+int vq_backward_gather(const float* grad_q, const float* grad_loss, const float* z, int layout, int64_t N, int D,
+                       int64_t HW, const float* E, int K, const int64_t* idx64, float coef, float* grad_z,
+                       void* stream);
+
+/*
  * Re-seed codes in place (maintenance).  ref: the per-code loops of
  * vqvae/ema_vector_quantizer.py:185-196 (reset_dead_codes: noise 0.2, scale 0.1), :262-274
  * (reset_low_usage_codes: noise 0.4, scale 0.2) and the new rows of :131-148 (expand_codebook:

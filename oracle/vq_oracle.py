@@ -220,3 +220,45 @@ def forward(z: np.ndarray, st: OracleState, commitment_cost: float, decay: float
     loss = np.float32(np.float32(commitment_cost) * np.float32(sq / (N * D)))
     return {"quantized": q_st, "loss": loss, "perplexity": perplexity(counts, N), "indices": idx.reshape(N, 1),
             "counts": counts, "dmin": dmin}
+
+
+def conv1x1(x: np.ndarray, W: np.ndarray, b) -> np.ndarray:
+    """nn.Conv2d(C, O, kernel_size=1) as the reference places it either side of the quantizer
+    (custom_vqgan.py:50-51): out[n, o, h, w] = sum_i W[o, i] x[n, i, h, w] + b[o]; float64
+    accumulation, float32 result."""
+    W2 = np.asarray(W, np.float64).reshape(W.shape[0], -1)
+    out = np.einsum("oi,nihw->nohw", W2, np.asarray(x, np.float64))
+    if b is not None:
+        out = out + np.asarray(b, np.float64)[None, :, None, None]
+    return out.astype(np.float32)
+
+
+def boundary(h: np.ndarray, Wq, bq, Wp, bp, st: OracleState, commitment_cost: float, decay: float = 0.95,
+             epsilon: float = 1e-5, temperature: float = 1.0, training: bool = True, grad_out=None,
+             grad_loss=None):
+    """quant_conv -> quantizer -> post_quant_conv (custom_vqgan.py:68, :81, :72) and, when grad_out /
+    grad_loss are given, the gradients autograd produces for them: the straight-through output passes
+    its gradient to the latents unchanged (ema_vector_quantizer.py:95), the commitment loss adds
+    grad_loss * 2 beta / (N D) * (z - q) (:92), the codebook receives nothing."""
+    h = _f32(h)
+    z = conv1x1(h, Wq, bq)
+    r = forward(z, st, commitment_cost, decay, epsilon, temperature, training)
+    q = r["quantized"]
+    res = {"out": conv1x1(q, Wp, bp), "loss": r["loss"], "perplexity": r["perplexity"], "indices": r["indices"],
+           "z": z}
+    if grad_out is None and grad_loss is None:
+        return res
+    B, D, H, W_ = z.shape
+    go = np.zeros(res["out"].shape, np.float64) if grad_out is None else np.asarray(grad_out, np.float64)
+    gl = 0.0 if grad_loss is None else float(grad_loss)
+    Wp2 = np.asarray(Wp, np.float64).reshape(Wp.shape[0], -1)
+    Wq2 = np.asarray(Wq, np.float64).reshape(Wq.shape[0], -1)
+    q64, z64, h64 = q.astype(np.float64), z.astype(np.float64), h.astype(np.float64)
+    gz = np.einsum("oi,nohw->nihw", Wp2, go) + gl * 2.0 * float(commitment_cost) / z.size * (z64 - q64)
+    res.update(grad_Wp=np.einsum("nohw,nihw->oi", go, q64).reshape(np.shape(Wp)).astype(np.float32),
+               grad_bp=go.sum((0, 2, 3)).astype(np.float32),
+               grad_z=gz.astype(np.float32),
+               grad_h=np.einsum("oi,nohw->nihw", Wq2, gz).astype(np.float32),
+               grad_Wq=np.einsum("nohw,nihw->oi", gz, h64).reshape(np.shape(Wq)).astype(np.float32),
+               grad_bq=gz.sum((0, 2, 3)).astype(np.float32))
+    return res

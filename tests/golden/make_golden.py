@@ -183,7 +183,46 @@ def g8():
                         embedding_abs_sum=np.float64(np.abs(st["state_embedding_weight"].astype(np.float64)).sum()))
 
 
+def g9():
+    """The quantizer between its two 1x1 convolutions, composed as vqvae/custom_vqgan.py does (:50-51
+    the layers, :68 quant_conv, :81 quantize, :72 post_quant_conv) from torch's own nn.Conv2d and the
+    reference quantizer (CustomVQGAN itself needs diffusers): forward outputs, post-step state and the
+    gradients of a * sum(out * w) + b * loss w.r.t. the encoder output and all four conv tensors."""
+    K, D = 64, 16
+    E = gauss(902, (K, D)) * np.float32(0.6)
+    h = gauss(901, (2, D, 4, 4))
+    w = gauss(903, (2, D, 4, 4))
+    Wq = gauss(904, (D, D, 1, 1)) * np.float32(0.3)
+    bq = gauss(905, (D,)) * np.float32(0.1)
+    Wp = gauss(906, (D, D, 1, 1)) * np.float32(0.3)
+    bp = gauss(907, (D,)) * np.float32(0.1)
+    for mode in ("train", "eval"):
+        q = make_ref(K, D, 3.0, 0.95, E)
+        q.train(mode == "train")
+        quant_conv = torch.nn.Conv2d(D, D, 1)
+        post_quant_conv = torch.nn.Conv2d(D, D, 1)
+        with torch.no_grad():
+            quant_conv.weight.copy_(torch.from_numpy(Wq)); quant_conv.bias.copy_(torch.from_numpy(bq))
+            post_quant_conv.weight.copy_(torch.from_numpy(Wp)); post_quant_conv.bias.copy_(torch.from_numpy(bp))
+        ht = torch.from_numpy(h).requires_grad_(True)
+        quant, loss, (perp, idx, _enc) = q(quant_conv(ht))
+        out = post_quant_conv(quant)
+        obj = 0.7 * (out * torch.from_numpy(w)).sum() + 1.3 * loss
+        obj.backward()
+        np.savez_compressed(os.path.join(HERE, f"g9_boundary_{mode}.npz"), E=E, h=h, w=w, Wq=Wq, bq=bq, Wp=Wp, bp=bp,
+                            a=np.float32(0.7), b=np.float32(1.3), beta=np.float32(3.0), decay=np.float64(0.95),
+                            out=out.detach().numpy().copy(), loss=np.float32(loss.item()),
+                            perplexity=np.float32(perp.item()), indices=idx.numpy().astype(np.int64).copy(),
+                            grad_h=ht.grad.numpy().copy(), grad_Wq=quant_conv.weight.grad.numpy().copy(),
+                            grad_bq=quant_conv.bias.grad.numpy().copy(),
+                            grad_Wp=post_quant_conv.weight.grad.numpy().copy(),
+                            grad_bp=post_quant_conv.bias.grad.numpy().copy(), **state_of(q))
+
+
 if __name__ == "__main__":
-    g1(); g2(); g3(); g4(); g6(); g8()
+    only = sys.argv[1:]
+    for fn in (g1, g2, g3, g4, g6, g8, g9):
+        if not only or fn.__name__ in only:
+            fn()
     total = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
     print("golden bytes:", total)

@@ -1,0 +1,165 @@
+"""GPU tests of QuantizerBoundary: quant_conv -> quantizer -> post_quant_conv with the second
+convolution folded into the codebook (a gather from E W^T + b)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, rel_err
+from oracle import vq_oracle as vo
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def make(K, D, beta, decay, E, Wq, bq, Wp, bp, dev):
+    from vq_vae_amd import QuantizerBoundary
+    m = QuantizerBoundary(latent_channels=D, n_embed=K, embed_dim=D, ema_decay=decay, commitment_loss_beta=beta).to(dev)
+    with torch.no_grad():
+        m.quantize.embedding.weight.copy_(torch.from_numpy(E))
+        m.quant_conv.weight.copy_(torch.from_numpy(Wq)); m.quant_conv.bias.copy_(torch.from_numpy(bq))
+        m.post_quant_conv.weight.copy_(torch.from_numpy(Wp)); m.post_quant_conv.bias.copy_(torch.from_numpy(bp))
+    return m
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_matches_reference_composition(mode, channels_last, dev):
+    """Golden g9: the reference quantizer between two torch 1x1 convolutions -- outputs, post-step
+    state and every gradient."""
+    g = np.load(f"{GOLDEN}/g9_boundary_{mode}.npz")
+    K, D = g["E"].shape
+    m = make(K, D, float(g["beta"]), float(g["decay"]), g["E"], g["Wq"], g["bq"], g["Wp"], g["bp"], dev)
+    m.train(mode == "train")
+    h = torch.from_numpy(g["h"]).to(dev)
+    if channels_last:
+        h = h.contiguous(memory_format=torch.channels_last)
+    h.requires_grad_(True)
+    out, loss, (perp, idx, enc) = m(h)
+    obj = float(g["a"]) * (out * torch.from_numpy(g["w"]).to(dev)).sum() + float(g["b"]) * loss
+    obj.backward()
+    torch.cuda.synchronize()
+    assert np.array_equal(idx.cpu().numpy(), g["indices"])
+    assert enc.shape == (idx.numel(), K)
+    assert rel_err(out.detach().cpu().numpy(), g["out"]) <= TOL
+    assert abs(loss.item() - g["loss"]) <= TOL * abs(g["loss"])
+    assert abs(perp.item() - g["perplexity"]) <= TOL * abs(g["perplexity"])
+    assert rel_err(h.grad.cpu().numpy(), g["grad_h"]) <= TOL
+    assert rel_err(m.quant_conv.weight.grad.cpu().numpy(), g["grad_Wq"]) <= TOL
+    assert rel_err(m.quant_conv.bias.grad.cpu().numpy(), g["grad_bq"]) <= TOL
+    assert rel_err(m.post_quant_conv.weight.grad.cpu().numpy(), g["grad_Wp"]) <= TOL
+    assert rel_err(m.post_quant_conv.bias.grad.cpu().numpy(), g["grad_bp"]) <= TOL
+    sd = m.state_dict()
+    assert rel_err(sd["quantize.embedding.weight"].cpu().numpy(), g["state_embedding_weight"]) <= TOL
+    assert rel_err(sd["quantize.ema_w"].cpu().numpy(), g["state_ema_w"]) <= TOL
+    assert rel_err(sd["quantize.ema_cluster_size"].cpu().numpy(), g["state_ema_cluster_size"]) <= TOL
+    assert np.array_equal(sd["quantize.usage_count"].cpu().numpy(), g["state_usage_count"])
+
+
+@pytest.mark.parametrize("shape", [(512, 64, (4, 64, 16, 16)), (1000, 48, (3, 48, 7, 9)), (8192, 256, (8, 256, 32, 32))])
+@pytest.mark.parametrize("filtered", [False, True])
+def test_folded_equals_unfused(shape, filtered, dev):
+    """The folded path against the same module run piece by piece (EMAVectorQuantizer.forward, then
+    torch's convolution on its output): identical indices and state, outputs and gradients to 1e-5."""
+    from vq_vae_amd import QuantizerBoundary
+    K, D, hs = shape
+    g = torch.Generator(device=dev).manual_seed(5)
+    h = torch.randn(*hs, device=dev, generator=g)
+    wt = torch.randn(*hs, device=dev, generator=g)
+    m = QuantizerBoundary(latent_channels=D, n_embed=K, embed_dim=D).to(dev)
+    with torch.no_grad():
+        m.quantize.embedding.weight.copy_(torch.randn(K, D, device=dev, generator=g) * 0.3)
+    if filtered:
+        m.quantize.search_mode = "filtered"
+        m.quantize.filtered_min_rows = 1
+        m.quantize.filtered_min_work = 1
+    import copy
+    m2 = copy.deepcopy(m)
+    m.train(); m2.train()
+    h1 = h.clone().requires_grad_(True)
+    out1, loss1, (perp1, idx1, _) = m(h1)
+    (0.5 * (out1 * wt).sum() + 2.0 * loss1).backward()
+    h2 = h.clone().requires_grad_(True)
+    q2, loss2, (perp2, idx2, _) = m2.quantize(m2.to_latents(h2))
+    out2 = m2.post_quant_conv(q2)
+    (0.5 * (out2 * wt).sum() + 2.0 * loss2).backward()
+    torch.cuda.synchronize()
+    assert torch.equal(idx1, idx2)
+    for a, b in zip(m.quantize.state_dict().values(), m2.quantize.state_dict().values()):
+        assert torch.equal(a, b)
+    assert rel_err(out1.detach().cpu().numpy(), out2.detach().cpu().numpy()) <= TOL
+    assert abs(loss1.item() - loss2.item()) <= 1e-6 * abs(loss2.item()) and torch.equal(perp1, perp2)
+    assert rel_err(h1.grad.cpu().numpy(), h2.grad.cpu().numpy()) <= TOL
+    for name in ("quant_conv", "post_quant_conv"):
+        a, b = getattr(m, name), getattr(m2, name)
+        assert rel_err(a.weight.grad.cpu().numpy(), b.weight.grad.cpu().numpy()) <= TOL, name
+        assert rel_err(a.bias.grad.cpu().numpy(), b.bias.grad.cpu().numpy()) <= TOL, name
+
+
+def test_oracle_on_random_problem(dev):
+    """Outputs and gradients against the CPU restatement of the three steps on a seeded problem."""
+    from vq_vae_amd import QuantizerBoundary
+    from inputs import gauss
+    K, D = 96, 32
+    E = gauss(11, (K, D)) * np.float32(0.5)
+    h = gauss(12, (3, D, 6, 5)); w = gauss(13, (3, D, 6, 5))
+    Wq = gauss(14, (D, D, 1, 1)) * np.float32(0.2); bq = gauss(15, (D,)) * np.float32(0.1)
+    Wp = gauss(16, (D, D, 1, 1)) * np.float32(0.2); bp = gauss(17, (D,)) * np.float32(0.1)
+    m = make(K, D, 2.0, 0.9, E, Wq, bq, Wp, bp, dev)
+    m.train()
+    ht = torch.from_numpy(h).to(dev).requires_grad_(True)
+    out, loss, (perp, idx, _) = m(ht, temperature=2.5)
+    (out * torch.from_numpy(w).to(dev)).sum().backward(retain_graph=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    st = vo.OracleState.fresh(E)
+    r = vo.boundary(h, Wq, bq, Wp, bp, st, 2.0, 0.9, 1e-5, 2.5, True, grad_out=w, grad_loss=1.0)
+    # the latents come from two different fp32 convolutions; the index comparison is exact unless a
+    # row sits within rounding of a tie, which this seed does not produce
+    assert np.array_equal(idx.cpu().numpy(), r["indices"])
+    assert rel_err(out.detach().cpu().numpy(), r["out"]) <= TOL
+    assert abs(loss.item() - r["loss"]) <= TOL * abs(r["loss"])
+    assert rel_err(ht.grad.cpu().numpy(), r["grad_h"]) <= TOL
+    assert rel_err(m.post_quant_conv.weight.grad.cpu().numpy(), r["grad_Wp"]) <= TOL
+    assert rel_err(m.post_quant_conv.bias.grad.cpu().numpy(), r["grad_bp"]) <= TOL
+    assert rel_err(m.quant_conv.weight.grad.cpu().numpy(), r["grad_Wq"]) <= TOL
+    assert rel_err(m.quant_conv.bias.grad.cpu().numpy(), r["grad_bq"]) <= TOL
+    assert rel_err(m.quantize.embedding.weight.detach().cpu().numpy(), st.embedding) <= TOL
+
+
+def test_dict_output_and_state_dict(dev):
+    """forward_dict returns device tensors only (keys of vqvae/custom_vqgan.py:107-114 on the quantizer
+    side); a CustomVQGAN-style state dict loads by name; eval under no_grad leaves the state alone."""
+    from vq_vae_amd import QuantizerBoundary
+    K, D = 128, 64
+    m = QuantizerBoundary(latent_channels=D, n_embed=K, embed_dim=D).to(dev)
+    h = torch.randn(2, 2 * D, 8, 8, device=dev)          # encoder with a log-variance half (:66-67)
+    m.train()
+    d = m.forward_dict(h)
+    assert set(d) == {"decoder_input", "commitment_loss", "indices", "perplexity", "entropy", "normalized_entropy"}
+    assert all(t.is_cuda for t in d.values())
+    assert d["decoder_input"].shape == (2, D, 8, 8) and d["indices"].shape == (128, K)
+    s = m.quantize.get_codebook_stats()
+    assert abs(d["entropy"].item() - s["entropy"]) <= 1e-6 * max(1.0, abs(s["entropy"]))
+    assert abs(d["normalized_entropy"].item() - s["normalized_entropy"]) <= 1e-6
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sd["encoder.conv_in.weight"] = torch.zeros(3)
+    m2 = QuantizerBoundary(latent_channels=D, n_embed=K, embed_dim=D).to(dev)
+    m2.load_vqgan_state_dict(sd)
+    m.eval(); m2.eval()
+    with torch.no_grad():
+        o1 = m(h)[0]
+        before = {k: v.clone() for k, v in m2.state_dict().items()}
+        o2 = m2(h)[0]
+    assert torch.equal(o1, o2)
+    for k, v in m2.state_dict().items():
+        assert torch.equal(v, before[k])
+    with pytest.raises(ValueError):
+        QuantizerBoundary(latent_channels=32, n_embed=K, embed_dim=D)
+    with pytest.raises(RuntimeError):
+        m(h.cpu())

@@ -166,3 +166,22 @@ def test_dense_port_matches_golden():
     assert abs(perp.item() - g["perplexity"]) <= 1e-6 * abs(g["perplexity"])
     assert rel_err(st["cs"].numpy(), g["state_ema_cluster_size"]) <= 1e-6
     assert rel_err(st["E"][:8].numpy(), g["state_embedding_weight_rows"]) <= 1e-6
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_boundary_convs_around_the_quantizer(mode):
+    """quant_conv -> quantizer -> post_quant_conv with gradients (golden g9: the reference quantizer
+    between two torch nn.Conv2d(.., 1) layers, composed as vqvae/custom_vqgan.py does)."""
+    g = load(f"g9_boundary_{mode}.npz")
+    st = vo.OracleState.fresh(g["E"])
+    r = vo.boundary(g["h"], g["Wq"], g["bq"], g["Wp"], g["bp"], st, float(g["beta"]), float(g["decay"]), 1e-5, 1.0,
+                    mode == "train", grad_out=float(g["a"]) * g["w"], grad_loss=float(g["b"]))
+    assert np.array_equal(r["indices"], g["indices"])
+    assert rel_err(r["out"], g["out"]) <= TOL
+    assert abs(r["loss"] - g["loss"]) <= TOL * abs(g["loss"])
+    assert abs(r["perplexity"] - g["perplexity"]) <= TOL * abs(g["perplexity"])
+    for name in ("grad_h", "grad_Wq", "grad_bq", "grad_Wp", "grad_bp"):
+        assert rel_err(r[name], g[name]) <= TOL, name
+    assert rel_err(st.embedding, g["state_embedding_weight"]) <= TOL
+    assert rel_err(st.ema_w, g["state_ema_w"]) <= TOL
+    assert rel_err(st.ema_cluster_size, g["state_ema_cluster_size"]) <= TOL

@@ -159,7 +159,7 @@ class EMAVectorQuantizer(nn.Module):
         return (self.search_mode == "filtered" and rows >= self.filtered_min_rows
                 and rows * self.num_embeddings * self.embedding_dim >= self.filtered_min_work)
 
-    def _run_step(self, z: torch.Tensor, temperature: float) -> ops.StepResult:
+    def _run_step(self, z: torch.Tensor, temperature: float, project=None) -> ops.StepResult:
         E = self.embedding.weight.data
         if not E.is_contiguous() or E.dtype != torch.float32:
             raise RuntimeError("embedding.weight must be a contiguous float32 tensor")
@@ -167,7 +167,7 @@ class EMAVectorQuantizer(nn.Module):
                                  beta=float(self.commitment_cost), decay=float(self.decay),
                                  epsilon=float(self.epsilon), temperature=float(temperature),
                                  training=self.training, ws=self._workspace(z.device),
-                                 stats_reduce=self._stats_reduce, filtered=self._use_filter(z))
+                                 stats_reduce=self._stats_reduce, filtered=self._use_filter(z), project=project)
 
     def forward(self, inputs, temperature=1.0):
         if not isinstance(inputs, torch.Tensor) or not inputs.is_cuda:
@@ -213,6 +213,23 @@ class EMAVectorQuantizer(nn.Module):
             "normalized_entropy": v[3] if active > 0 else 0,
             "total_usage": v[4],
         }
+
+    def codebook_stats_device(self) -> torch.Tensor:
+        """The numbers of get_codebook_stats as a float64 device tensor [active_size, utilization,
+        entropy, normalized_entropy, total_usage] -- no copy to the host, no synchronisation (the
+        reference reads them with four .item() calls on every forward that returns a dict,
+        vqvae/custom_vqgan.py:102-104).  Entropies are 0 when no code is active, as in :216-221."""
+        cs = self.ema_cluster_size
+        if not cs.is_cuda:
+            raise RuntimeError("codebook_stats_device needs the module on the GPU")
+        lib = load()
+        out = torch.empty(5, dtype=torch.float64, device=cs.device)
+        check(lib.vq_cluster_stats(ops._ptr(cs), ops._ptr(self.usage_count.to(cs.device)), self.num_embeddings,
+                                   ops._ptr(out), ops._stream(cs.device)), "vq_cluster_stats")
+        active = out[0] > 0
+        zero = torch.zeros((), dtype=torch.float64, device=cs.device)
+        return torch.stack([out[0], out[0] / self.num_embeddings, torch.where(active, out[2], zero),
+                            torch.where(active, out[3], zero), out[4]])
 
     def last_step_counters(self) -> dict:
         """Counters of the most recent forward (one small device-to-host copy, i.e. a sync): rows that

@@ -48,7 +48,7 @@ def _rows_view(z: torch.Tensor):
         B, C, H, W = z.shape
         rows = z.permute(0, 2, 3, 1).reshape(B * H * W, C)
         if rows.data_ptr() == z.data_ptr():          # a view, as expected
-            return rows, (lambda t: t.view(B, H, W, C).permute(0, 3, 1, 2))
+            return rows, (lambda t: t.view(B, H, W, t.shape[-1]).permute(0, 3, 1, 2))
     return None, None
 
 
@@ -255,6 +255,16 @@ def embed_sums(z: torch.Tensor, idx32: torch.Tensor, K: int, ws: Workspace, code
     return slabs, nslab
 
 
+def code_sums(x: torch.Tensor, idx32: torch.Tensor, K: int, ws: Workspace) -> torch.Tensor:
+    """sums[k, :] = sum of the rows of x assigned to code k (the scatter-add of the EMA update, applied
+    to any per-latent tensor: (B, C, H, W) in either memory format, or (N, C))."""
+    if x.dtype != torch.float32:
+        x = x.float()
+    rows, _ = _rows_view(x)
+    slabs, _ = embed_sums(rows if rows is not None else x, idx32, K, ws)
+    return reduce_slabs(slabs)
+
+
 def reduce_slabs(slabs: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = _lib.load()
     nslab, K, D = slabs.shape
@@ -364,11 +374,68 @@ def gather_st(z: torch.Tensor, E: torch.Tensor, idx64: torch.Tensor, ws: Workspa
     return q, lp, n_partial
 
 
+def gather_project(z: torch.Tensor, E: torch.Tensor, idx64: torch.Tensor, P: torch.Tensor, ws: Workspace):
+    """vq_gather_project: out[n] = P[idx[n]] in z's layout (P = the codebook carried through the 1x1
+    convolution that follows the quantizer, vqvae/custom_vqgan.py:72) and the loss partials of
+    |E[idx[n]] - z[n]|^2.  Returns (out, loss_partial, n_partial)."""
+    lib = _lib.load()
+    if z.dtype != torch.float32:
+        z = z.float()
+    rows, back = _rows_view(z)
+    if rows is not None and z.shape[1] == E.shape[1]:
+        out, lp, n_partial = gather_project(rows, E, idx64, P, ws)
+        return back(out), lp, n_partial
+    z = _f32c(z, "latents")
+    E = _f32c(E, "codebook")
+    P = _f32c(P, "projected codebook")
+    K, D = E.shape
+    if P.dim() != 2 or P.shape[0] != K:
+        raise RuntimeError(f"projected codebook must be ({K}, D'), got {tuple(P.shape)}")
+    DP = P.shape[1]
+    layout, N, HW = _shape_of(z, D)
+    shape = (z.shape[0], DP, z.shape[2], z.shape[3]) if layout == LAYOUT_NCHW else (N, DP)
+    out = torch.empty(shape, dtype=torch.float32, device=z.device)
+    n_partial = lib.vq_search_blocks(N)
+    lp = ws.get("loss_partial", lib.vq_loss_partial_bytes(N), torch.float32)
+    check(lib.vq_gather_project(_ptr(z), layout, N, D, HW, _ptr(E), K, _ptr(idx64), _ptr(P), DP, _ptr(out), _ptr(lp),
+                                _stream(z.device)), "vq_gather_project")
+    return out, lp, n_partial
+
+
+def backward_gather(grad_q, grad_loss, z: torch.Tensor, E: torch.Tensor, idx64: torch.Tensor, coef: float) -> torch.Tensor:
+    """vq_backward_gather: grad_z = grad_q + grad_loss * coef * (z - E[idx]), in z's memory format."""
+    lib = _lib.load()
+    _require_cuda(z, "latents")
+    rows, back = _rows_view(z)
+    if rows is not None:
+        gq = None
+        if grad_q is not None:
+            gq = grad_q.float().contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(rows.shape)
+        return back(backward_gather(gq, grad_loss, rows, E, idx64, coef))
+    z = _f32c(z, "latents")
+    E = _f32c(E, "codebook")
+    K, D = E.shape
+    layout, N, HW = _shape_of(z, D)
+    gq = None if grad_q is None else _f32c(grad_q, "grad_quantized")
+    if gq is not None and gq.shape != z.shape:
+        raise RuntimeError(f"grad_quantized has shape {tuple(gq.shape)}, latents {tuple(z.shape)}")
+    gl = None if grad_loss is None else _f32c(grad_loss, "grad_loss")
+    grad_z = torch.empty_like(z)
+    check(lib.vq_backward_gather(_ptr(gq), _ptr(gl), _ptr(z), layout, N, D, HW, _ptr(E), K, _ptr(idx64), float(coef),
+                                 _ptr(grad_z), _stream(z.device)), "vq_backward_gather")
+    return grad_z
+
+
 def quantize_step(z: torch.Tensor, E: torch.Tensor, ema_w, cluster_size, usage, *, beta: float, decay: float,
                   epsilon: float, temperature: float, training: bool, ws: Workspace, want_dmin: bool = False,
-                  stats_reduce=None, search_events=None, filtered: bool = False) -> StepResult:
+                  stats_reduce=None, search_events=None, filtered: bool = False,
+                  project: Optional[torch.Tensor] = None) -> StepResult:
     """One full forward of the quantizer: search, gather, loss, histogram, perplexity and, in
     training mode, the EMA update of (usage, cluster_size, ema_w, E) in place.
+
+    ``project`` (K x D'), when given, is the codebook carried through the 1x1 convolution that follows
+    the quantizer: ``quantized`` in the result is then that convolution's output (gathered rows of
+    ``project``) and the N x D tensor of quantized latents is never written.
 
     ``stats_reduce(counts_i32, dw_or_None, N_local) -> (counts_i64, dw, N_total)`` is the hook of the
     data-parallel mode: it sums the EMA statistics over ranks before the update (the exchange
@@ -383,11 +450,15 @@ def quantize_step(z: torch.Tensor, E: torch.Tensor, ema_w, cluster_size, usage, 
         # channels_last input: the whole step runs on the (N, D) view, the output gets z's format back
         out = quantize_step(rows, E, ema_w, cluster_size, usage, beta=beta, decay=decay, epsilon=epsilon,
                             temperature=temperature, training=training, ws=ws, want_dmin=want_dmin,
-                            stats_reduce=stats_reduce, search_events=search_events, filtered=filtered)
+                            stats_reduce=stats_reduce, search_events=search_events, filtered=filtered,
+                            project=project)
         out.quantized = back(out.quantized)
         return out
-    r = search(z, E, ws, temperature=temperature, want_quantized=True, want_dmin=want_dmin, events=search_events,
-               filtered=filtered)
+    r = search(z, E, ws, temperature=temperature, want_quantized=project is None, want_dmin=want_dmin,
+               events=search_events, filtered=filtered)
+    if project is not None:
+        # the codebook is still the one the search saw: the EMA update comes last
+        r["quantized"], r["loss_partial"], r["n_partial"] = gather_project(z, E, r["indices"], project, ws)
     N = r["N"]
     counts = ws.get("counts", K * 4, torch.int32)
     histogram(r["idx32"][:N], K, ws, out=counts)
