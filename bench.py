@@ -125,6 +125,11 @@ def main() -> None:
                          "U(-1/K, 1/K) initialisation, which collapses onto a few codes (skewed EMA scatter)")
     args = ap.parse_args()
 
+    if os.environ.get("BENCH_WATCHDOG"):
+        # debugging aid: dump every thread's stack and exit if the run takes longer than this many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["BENCH_WATCHDOG"]), exit=True)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -167,34 +172,37 @@ def main() -> None:
 
     ev_pairs = []
 
-    def step(timed: bool, filtered: bool = False):
+    def step(timed: bool, filtered: bool = False, local: bool = False):
         ev = None
         if timed:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev_pairs.append(ev)
         return ops.quantize_step(z, E, ema_w, cs, usage, beta=BETA, decay=DECAY, epsilon=EPS, temperature=1.0,
-                                 training=True, ws=ws, stats_reduce=stats_reduce, search_events=ev, filtered=filtered)
+                                 training=True, ws=ws, stats_reduce=None if local else stats_reduce,
+                                 search_events=ev, filtered=filtered)
 
     def timed_run(filtered: bool, across_ranks: bool = True) -> float:
         """W untimed + K timed steps, barrier + synchronize on both sides, max over ranks (seconds).
-        across_ranks=False times this rank alone (no barrier / max; the step's own all-reduce stays)."""
+        across_ranks=False times this rank alone: no barrier, no max, and the EMA statistics are not
+        summed over the ranks either, so the run contains no collective at all."""
         sync = world > 1 and across_ranks
+        local = not across_ranks
         for _ in range(args.warmup):
-            step(False, filtered)
+            step(False, filtered, local)
         torch.cuda.synchronize()
         if sync:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            step(True, filtered)
+            step(True, filtered, local)
         torch.cuda.synchronize()
         if sync:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if sync:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
@@ -224,7 +232,7 @@ def main() -> None:
                 "ms_per_step": f_elapsed / args.steps * 1e3, "search_ms": f_search_ms,
                 "indices_identical_to_fp32_search": same, "rows_compared": rows,
                 "effective_tflops": 2.0 * rows * K * D / (f_search_ms * 1e-3) / 1e12,
-                "timing": "max over ranks" if world == 1 else "rank 0 only",
+                "timing": "max over ranks" if world == 1 else "rank 0 only, rank-local EMA statistics",
                 "note": "opt-in search_mode='filtered': bf16 MFMA pass under a proven error bound selects the candidates, "
                         "fp32 chain decides; outputs bit-identical to the fp32 search"}
 

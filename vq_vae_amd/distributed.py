@@ -22,6 +22,18 @@ def counts_to_int64(counts_i32: torch.Tensor) -> torch.Tensor:
     return counts_i32.to(torch.int64) & 0xFFFFFFFF
 
 
+def _all_reduce(t: torch.Tensor, op, group) -> None:
+    """dist.all_reduce in place.  RCCL reduces device tensors directly; the gloo backend (CPU tests and
+    rehearsals of the multi-rank path on a box with fewer GPUs) gets a host copy, because its own
+    handling of device tensors stalls when several ranks share one GPU."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+
+
 def make_stats_reduce(group: Optional[dist.ProcessGroup] = None, uneven_rows: bool = False):
     """Returns the ``stats_reduce`` hook of ``ops.quantize_step`` for data-parallel training.
 
@@ -37,14 +49,14 @@ def make_stats_reduce(group: Optional[dist.ProcessGroup] = None, uneven_rows: bo
         if uneven_rows:
             buf = torch.cat([counts_to_int64(counts_i32),
                              torch.tensor([n_local], dtype=torch.int64, device=counts_i32.device)])
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+            _all_reduce(buf, dist.ReduceOp.SUM, group)
             counts64, n_total = buf[:-1].contiguous(), int(buf[-1].item())
         else:
             counts64 = counts_to_int64(counts_i32)
-            dist.all_reduce(counts64, op=dist.ReduceOp.SUM, group=group)
+            _all_reduce(counts64, dist.ReduceOp.SUM, group)
             n_total = n_local * world
         if dw is not None:
-            dist.all_reduce(dw, op=dist.ReduceOp.SUM, group=group)
+            _all_reduce(dw, dist.ReduceOp.SUM, group)
         return counts64, dw, n_total
 
     return reduce
@@ -61,7 +73,7 @@ def merge_packed_winners(packed_i64: torch.Tensor, group: Optional[dist.ProcessG
     """(min-distance, index) all-reduce of the row-sharded search: the packed int64 keys order
     exactly as torch.argmin would order the unsharded distance row (NaN first, then distance,
     then lowest index), so an elementwise MIN over ranks picks the global winner."""
-    dist.all_reduce(packed_i64, op=dist.ReduceOp.MIN, group=group)
+    _all_reduce(packed_i64, dist.ReduceOp.MIN, group)
     return packed_i64
 
 
@@ -120,5 +132,5 @@ def sharded_quantize_step(z: torch.Tensor, E_shard: torch.Tensor, ema_w_shard, c
 
 def _all_reduce_sum(t: torch.Tensor, group) -> torch.Tensor:
     t = t.clone()
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    _all_reduce(t, dist.ReduceOp.SUM, group)
     return t
