@@ -6,7 +6,7 @@ N x K one-hot matrix, and two more dense products for the gather and the EMA sum
 (vqvae/ema_vector_quantizer.py:35-106).  This script writes that formulation out with stock torch
 ops (rocBLAS sgemm and elementwise kernels), runs it on cuda:0 at batch sizes whose N x K matrices
 fit comfortably, and prints latent vectors per second next to this library's step on the same
-inputs.  It is a yardstick for DESIGN.md, not part of the product or of the tests.
+inputs.  It is a yardstick, not part of the product or of the tests.
 
     python tools/torch_formulation_gpu.py [rows ...]        (default: 65536 262144 1048576)
 """
