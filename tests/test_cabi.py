@@ -188,6 +188,9 @@ def test_filtered_entry_argument_checks():
     assert unsupported != 0 and unsupported != call(z=nul)
     assert call(D=32) == unsupported and call(T=0.0) == unsupported and call(T=float("inf")) == unsupported
     assert call(q=p, code_base=512) == unsupported
-    assert lib.vq_filter_work_bytes(1000) == 168 * 1000 and lib.vq_filter_work_bytes(1001) == 168 * 1004
+    # 168 bytes per row (rounded up to 4 rows); batches of fewer than 192 x 512 rows add the key lists of a
+    # divided first pass (32 bytes per row and part, up to 8 parts)
+    assert lib.vq_filter_work_bytes(1 << 20) == 168 << 20 and lib.vq_filter_work_bytes((1 << 20) + 1) == 168 * ((1 << 20) + 4)
+    assert lib.vq_filter_work_bytes(1000) == (168 + 32 * 8) * 1000 and lib.vq_filter_work_bytes(65536) == (168 + 32 * 2) * 65536
     assert lib.vq_filter_image_bytes(8192, 256) == 256 * 17 * 1024 + 256 + 8192 * 32 + 256 * 4 * 33
     assert lib.vq_filter_loss_partial_bytes(1 << 20) > lib.vq_loss_partial_bytes(1 << 20)

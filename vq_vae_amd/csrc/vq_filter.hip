@@ -71,6 +71,25 @@ __device__ __forceinline__ float bf16_hi(uint32_t p) { return __uint_as_float(p 
 __host__ __device__ inline int fq_steps(int D) { return D / 16 + 1; }
 __host__ __device__ inline int fq_tiles(int K) { return (K + 32 * FQ_STAGE_TILES - 1) / (32 * FQ_STAGE_TILES) * FQ_STAGE_TILES; }
 
+// Codebook split of a filter launch that has too few row workgroups to fill the chip: the sweep is
+// divided over blockIdx.y into S parts of sps stages each (at least two stages per part); every part
+// leaves its own key lists and vqf_merge_kernel folds them into the lists an undivided sweep would
+// have produced.  Evaluated on the host (first pass: the row count is known) and on the device
+// (second pass: the row count is a counter in device memory) with the same result.
+constexpr int FQ_MAX_SPLIT = 8;
+// parts wanted for a launch of `wgs` row workgroups, before the codebook's size limits it
+__host__ __device__ inline int fq_split_wanted(int64_t wgs) {
+  const int s = wgs >= 192 ? 1 : (int)(256 / (wgs > 0 ? wgs : 1));
+  return s > FQ_MAX_SPLIT ? FQ_MAX_SPLIT : s;
+}
+__host__ __device__ inline void fq_split(int64_t wgs, int nstages, int& S, int& sps) {
+  int s = fq_split_wanted(wgs);
+  if (s > nstages / 2) s = nstages / 2;
+  if (s < 1) s = 1;
+  sps = (nstages + s - 1) / s;
+  S = (nstages + sps - 1) / sps;   // <= s
+}
+
 // ---------------------------------------------------------------------------------------
 // mu[c] = mean over the codes of E[k][c], in two steps with a fixed summation order: 32 row
 // ranges x D/64 channel groups of partial sums (coalesced 256-byte row segments), then one thread
@@ -251,6 +270,12 @@ __global__ __launch_bounds__(512, 2) void vqf_filter_kernel(FilterArgs a) {
     if (nrows * 8 > a.N) return;  // too many unsettled rows: the fp32 kernel redoes the batch
   }
   if ((int64_t)blockIdx.x * FQ_WG_ROWS >= nrows) return;  // list mode: the grid covers the worst case
+  int nsplit, sps;
+  fq_split((nrows + FQ_WG_ROWS - 1) / FQ_WG_ROWS, a.nstages, nsplit, sps);
+  const int part = blockIdx.y;
+  if (part >= nsplit) return;
+  const int st_begin = part * sps;
+  const int st_end = st_begin + sps < a.nstages ? st_begin + sps : a.nstages;
 
   // the codebook mean, through LDS (behind the two stage buffers); the barrier comes before the
   // first DMA is issued, so that it does not wait for that copy
@@ -258,7 +283,7 @@ __global__ __launch_bounds__(512, 2) void vqf_filter_kernel(FilterArgs a) {
   if (threadIdx.x < D) mus[threadIdx.x] = a.mu[threadIdx.x];
   __syncthreads();
 
-  fq_stage_copy<D>(a.image, 0, flds, wave, lane);   // lands while z is being loaded
+  fq_stage_copy<D>(a.image, st_begin, flds, wave, lane);   // lands while z is being loaded
 
   float hmax[5];
 #pragma unroll
@@ -338,7 +363,7 @@ __global__ __launch_bounds__(512, 2) void vqf_filter_kernel(FilterArgs a) {
     {
       // written now rather than after the sweep: 16 registers less to carry through it
       const int64_t pos = row0 + ct * 32 + j;
-      if (g == 0 && pos < nrows) {
+      if (g == 0 && pos < nrows && part == 0) {
         a.rowaux[2 * pos] = f32x4{cst, c1, c2, c3};
         a.rowaux[2 * pos + 1] = f32x4{c4, c5, 0.0f, 0.0f};
       }
@@ -355,7 +380,7 @@ __global__ __launch_bounds__(512, 2) void vqf_filter_kernel(FilterArgs a) {
     }
     zb[ct][ZS] = extra;
   }
-  if (!listed) {  // the first level sees every row of the batch
+  if (!listed && part == 0) {  // the first level sees every row of the batch
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
       const uint32_t o = (uint32_t)__shfl_xor((int)zmax_bits, off);
@@ -375,9 +400,9 @@ __global__ __launch_bounds__(512, 2) void vqf_filter_kernel(FilterArgs a) {
   __syncthreads();  // stage 0 has landed
 
   int cur = 0;
-  for (int st = 0; st < a.nstages; ++st) {
+  for (int st = st_begin; st < st_end; ++st) {
     char* buf = flds + cur * STAGE_B;
-    if (st + 1 < a.nstages) fq_stage_copy<D>(a.image, st + 1, flds + (cur ^ 1) * STAGE_B, wave, lane);
+    if (st + 1 < st_end) fq_stage_copy<D>(a.image, st + 1, flds + (cur ^ 1) * STAGE_B, wave, lane);
     const u32x4* A = reinterpret_cast<const u32x4*>(buf) + lane;
 #pragma unroll
     for (int t = 0; t < FQ_STAGE_TILES; ++t) {
@@ -404,10 +429,51 @@ __global__ __launch_bounds__(512, 2) void vqf_filter_kernel(FilterArgs a) {
     if (pos < nrows) {
 #pragma unroll
       for (int q = 0; q < R / 4; ++q)
-        a.cand[(pos * 2 + g) * (R / 4) + q] = u32x4{__float_as_uint(m[ct][4 * q]), __float_as_uint(m[ct][4 * q + 1]),
+        a.cand[((pos * nsplit + part) * 2 + g) * (R / 4) + q] = u32x4{__float_as_uint(m[ct][4 * q]), __float_as_uint(m[ct][4 * q + 1]),
                                                    __float_as_uint(m[ct][4 * q + 2]), __float_as_uint(m[ct][4 * q + 3])};
     }
   }
+}
+
+// Folds the key lists of a divided sweep: for every (row, lane half) the R smallest of the parts'
+// S x R keys, sorted -- exactly the list one sweep over the whole codebook leaves (the R smallest
+// of a union are among the R smallest of each part).
+template <int R>
+__global__ __launch_bounds__(256) void vqf_merge_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out, int64_t N,
+                                                        int nstages, const int32_t* __restrict__ control, int count_word) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t pos = t >> 1;
+  const int g = (int)(t & 1);
+  int64_t nrows = N;
+  if (count_word >= 0) {
+    nrows = control[count_word];
+    if (nrows * 8 > N) return;
+  }
+  if (control[VQ_CTL_CB_FLAG] != 0 || pos >= nrows) return;
+  int nsplit, sps;
+  fq_split((nrows + FQ_WG_ROWS - 1) / FQ_WG_ROWS, nstages, nsplit, sps);
+  uint32_t m[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) m[i] = 0x7f800000u;
+  for (int y = 0; y < nsplit; ++y) {
+#pragma unroll
+    for (int q = 0; q < R / 4; ++q) {
+      const u32x4 v = in[((pos * nsplit + y) * 2 + g) * (R / 4) + q];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint32_t x = v[j];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          const uint32_t lo = m[i] < x ? m[i] : x;
+          x = m[i] < x ? x : m[i];
+          m[i] = lo;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < R / 4; ++q)
+    out[(pos * 2 + g) * (R / 4) + q] = u32x4{m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]};
 }
 
 struct VerifyArgs {
@@ -592,8 +658,14 @@ int launch_filter(const FilterArgs& a, hipStream_t s) {
                                      (int)lds_bytes));
     attr_done[dev & 63] = true;
   }
-  const int64_t blocks = (a.N + FQ_WG_ROWS - 1) / FQ_WG_ROWS;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds_bytes, s, a);
+  // first pass: every row, the split known here; second pass (list mode): at most N/8 rows reach it,
+  // and the kernel derives its split from the counter, so the grid covers the largest one
+  const int64_t rows = a.row_list ? (a.N + 7) / 8 : a.N;
+  const int64_t blocks = (rows + FQ_WG_ROWS - 1) / FQ_WG_ROWS;
+  int nsplit = 1, sps = a.nstages;
+  if (a.row_list) nsplit = a.nstages / 2 < FQ_MAX_SPLIT ? (a.nstages / 2 > 0 ? a.nstages / 2 : 1) : FQ_MAX_SPLIT;
+  else fq_split(blocks, a.nstages, nsplit, sps);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)nsplit), dim3(512), lds_bytes, s, a);
   return vq_hip_status(hipGetLastError());
 }
 
@@ -612,6 +684,20 @@ int launch_verify(const VerifyArgs& v, bool nchw, hipStream_t s) {
   if (nchw) hipLaunchKernelGGL((vqf_verify_kernel<true, R>), dim3(vb), dim3(256), 0, s, v);
   else hipLaunchKernelGGL((vqf_verify_kernel<false, R>), dim3(vb), dim3(256), 0, s, v);
   return vq_hip_status(hipGetLastError());
+}
+
+template <int R>
+int launch_merge(const u32x4* in, u32x4* out, int64_t N, int64_t rows_max, int nstages, const int32_t* control,
+                 int count_word, hipStream_t s) {
+  const unsigned mb = (unsigned)((2 * rows_max + 255) / 256);
+  hipLaunchKernelGGL((vqf_merge_kernel<R>), dim3(mb), dim3(256), 0, s, in, out, N, nstages, control, count_word);
+  return vq_hip_status(hipGetLastError());
+}
+
+// rows of the first pass's divided sweep need S lists each: they go behind the fixed regions
+inline size_t fq_split_extra_bytes(int64_t N) {
+  const int S = fq_split_wanted((N + FQ_WG_ROWS - 1) / FQ_WG_ROWS);   // the largest split any codebook allows for this N
+  return S > 1 ? (size_t)((N + 3) & ~(int64_t)3) * 32 * S : 0;
 }
 
 }  // namespace
@@ -649,8 +735,11 @@ int vq_filter_prep(const float* E, const float* e2, int K, int D, void* fimage, 
 }
 
 // Work buffer: [keys of pass 1: N x 32][row terms: N x 32][list A: N x 4][keys of pass 2: N x 64][row terms: N x 32][list B: N x 4]
-// (regions laid out for N rounded up to a multiple of 4, which keeps each 16-byte aligned)
-size_t vq_filter_work_bytes(int64_t N) { return N > 0 ? (size_t)((N + 3) & ~(int64_t)3) * 168 : 256; }
+// (regions laid out for N rounded up to a multiple of 4, which keeps each 16-byte aligned), then, for
+// batches small enough that the first pass divides its sweep, the S key lists per row of that pass.
+size_t vq_filter_work_bytes(int64_t N) {
+  return N > 0 ? (size_t)((N + 3) & ~(int64_t)3) * 168 + fq_split_extra_bytes(N) : 256;
+}
 
 // Internal: filter + verify, two levels.  Settled rows get idx / dmin; rows for the exact kernel
 // are appended to nf_rows (control[VQ_CTL_NF_COUNT]); rows that overflowed both levels are left
@@ -671,13 +760,20 @@ int vq_filter_verify_launch(const float* z, int nchw, int64_t N, int D, int64_t 
   f.hdr = reinterpret_cast<const uint32_t*>(static_cast<const char*>(fimage) + (size_t)tiles * fq_steps(D) * 1024);
   f.mu = reinterpret_cast<const float*>(reinterpret_cast<const char*>(f.hdr) + 256 + (size_t)tiles * 32 * 32);
   f.N = N; f.HW = nchw ? HW : 1; f.nstages = tiles / FQ_STAGE_TILES;
-  f.cand = reinterpret_cast<u32x4*>(w);
+  u32x4* keys1 = reinterpret_cast<u32x4*>(w);
+  int split1, sps1;
+  fq_split((N + FQ_WG_ROWS - 1) / FQ_WG_ROWS, f.nstages, split1, sps1);
+  f.cand = split1 > 1 ? reinterpret_cast<u32x4*>(w + NP * 168) : keys1;
   f.rowaux = reinterpret_cast<f32x4*>(w + NP * 32);
   f.control = control;
   int rc = dispatch_filter<4>(f, D, nchw != 0, s);
   if (rc != VQ_OK) return rc;
+  if (split1 > 1) {
+    rc = launch_merge<4>(f.cand, keys1, N, N, f.nstages, control, -1, s);
+    if (rc != VQ_OK) return rc;
+  }
   VerifyArgs v{};
-  v.z = z; v.E = E; v.e2 = e2; v.cand = f.cand; v.rowaux = f.rowaux; v.N = N; v.HW = f.HW; v.K = K; v.D = D; v.T = T;
+  v.z = z; v.E = E; v.e2 = e2; v.cand = keys1; v.rowaux = f.rowaux; v.N = N; v.HW = f.HW; v.K = K; v.D = D; v.T = T;
   v.code_base = code_base; v.idx64 = idx64; v.idx32 = idx32; v.dmin = dmin; v.nf_rows = nf_rows; v.control = control;
   v.aux = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(f.hdr) + 256);
   v.ovf_rows = listA; v.ovf_word = VQ_CTL_OVF_COUNT;
@@ -689,7 +785,13 @@ int vq_filter_verify_launch(const float* z, int nchw, int64_t N, int D, int64_t 
   f.row_list = listA; f.count_word = VQ_CTL_OVF_COUNT;
   rc = dispatch_filter<8>(f, D, nchw != 0, s);
   if (rc != VQ_OK) return rc;
-  v.cand = f.cand; v.rowaux = f.rowaux; v.row_list = listA; v.count_word = VQ_CTL_OVF_COUNT;
+  // its lists (one per part of the sweep; rows x parts <= N) are folded into the unused tail of the
+  // second pass's row-term region (at most N/8 rows reach this pass: row terms N x 4 bytes, folded
+  // lists N x 8 bytes of the region's N x 32)
+  u32x4* keys2 = reinterpret_cast<u32x4*>(w + NP * 140);
+  rc = launch_merge<8>(f.cand, keys2, N, (N + 7) / 8, f.nstages, control, VQ_CTL_OVF_COUNT, s);
+  if (rc != VQ_OK) return rc;
+  v.cand = keys2; v.rowaux = f.rowaux; v.row_list = listA; v.count_word = VQ_CTL_OVF_COUNT;
   v.ovf_rows = listB; v.ovf_word = VQ_CTL_OVF2_COUNT;
   return launch_verify<8>(v, nchw != 0, s);
 }
