@@ -102,8 +102,9 @@ class EMAVectorQuantizer(nn.Module):
     #: on large batches; shapes it does not cover (D not in {64,128,256}, K > 8192) use "fp32".
     search_mode = "fp32"
     #: "filtered" pays from about this many latent vectors and this much work (rows x codes x channels)
-    #: upwards -- its pipeline of kernels has a floor of ~0.4 ms; below either, the fp32 search runs
-    filtered_min_rows = 65536
+    #: upwards (measured crossover: 0.55 against 0.63 ms at 16 Ki rows, K=8192, D=256) -- its pipeline
+    #: of kernels has a floor of ~0.15-0.5 ms; below either, the fp32 search runs
+    filtered_min_rows = 16384
     filtered_min_work = 1 << 35
 
     def __init__(self, num_embeddings, embedding_dim, commitment_cost, decay=0.95, epsilon=1e-5):
