@@ -257,6 +257,18 @@ def test_graphed_step_equals_eager(dev):
     print(f"K=512 D=64 N=4096 training step: eager {t_eager * 1e6:.0f} us, graph replay {t_graph * 1e6:.0f} us")
     with pytest.raises(RuntimeError):
         g(torch.zeros(2, D, 4, 4, device=dev))
+    # outside the tested envelope the capture refuses; a captured module refuses its own forward
+    with pytest.raises(RuntimeError):
+        graphed(batches[0])
+    used = make(K, D, 3.0, 0.95, E, dev); used.train(); used(batches[0])
+    with pytest.raises(RuntimeError):
+        GraphedQuantizer(used, batches[0])
+    evalm = make(K, D, 3.0, 0.95, E, dev); evalm.eval()
+    with pytest.raises(RuntimeError):
+        GraphedQuantizer(evalm, batches[0])
+    wide = make(64, 256, 3.0, 0.95, gauss(62, (64, 256)), dev); wide.train()
+    with pytest.raises(RuntimeError):
+        GraphedQuantizer(wide, torch.zeros(2, 256, 4, 4, device=dev))
 
 
 def test_last_step_counters_report_nonfinite_rows(dev):

@@ -41,3 +41,35 @@ for filt in (False, True):
     print(f'K=65536 on one GPU, N=524288, filtered={filt}: {timeit(lambda: ops.search(z, E65, ws, filtered=filt), reps=3, warm=1):.2f} ms', flush=True)
 a = ops.search(z, E65, ws)['indices'].clone(); b = ops.search(z, E65, ws, filtered=True)['indices']
 print('K=65536 indices equal:', bool(torch.equal(a, b)))
+# ---- config 4: the module inside a training step at a per-GPU batch of 64 images (64 Ki latents):
+# forward + backward of the quantizer, then the same with the convolutions either side (QuantizerBoundary)
+from vq_vae_amd import QuantizerBoundary
+del z, E65
+h = torch.randn(64, D, 32, 32, device=dev, generator=g)
+wt = torch.randn(64, D, 32, 32, device=dev, generator=g)
+for mode in ('fp32', 'filtered'):
+    q = EMAVectorQuantizer(K, D, 3.0).to(dev)
+    with torch.no_grad(): q.embedding.weight.copy_(E)
+    q.search_mode = mode; q.train()
+    hh = h.clone().requires_grad_(True)
+    def fb():
+        out, loss, _ = q(hh)
+        ((out * wt).sum() + loss).backward()
+        hh.grad = None
+    with torch.no_grad():
+        t_f = timeit(lambda: q(h), reps=20, warm=3)
+    t_fb = timeit(fb, reps=20, warm=3)
+    print(f'config 4, module at 64 Ki latents, {mode}: forward {t_f:.3f} ms, forward+backward {t_fb:.3f} ms', flush=True)
+    b = QuantizerBoundary(D, K, D).to(dev)
+    with torch.no_grad(): b.quantize.embedding.weight.copy_(E)
+    b.quantize.search_mode = mode; b.train()
+    def fb_fused():
+        out, loss, _ = b(hh)
+        ((out * wt).sum() + loss).backward()
+        hh.grad = None; b.zero_grad(set_to_none=True)
+    def fb_unfused():
+        qq, loss, _ = b.quantize(b.to_latents(hh))
+        out = b.post_quant_conv(qq)
+        ((out * wt).sum() + loss).backward()
+        hh.grad = None; b.zero_grad(set_to_none=True)
+    print(f'config 4, quant_conv -> quantizer -> post_quant_conv, {mode}: forward+backward {timeit(fb_unfused, reps=10, warm=3):.3f} ms with torch convolutions, {timeit(fb_fused, reps=10, warm=3):.3f} ms folded', flush=True)

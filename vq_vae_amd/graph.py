@@ -19,8 +19,16 @@ class GraphedQuantizer:
 
     ``__call__(z)`` copies ``z`` into the captured input buffer, replays the graph and returns
     ``(quantized, loss, perplexity, indices)`` -- tensors that the next replay overwrites.
-    The mode (train / eval), temperature and search mode are fixed at capture time.  Not available
-    together with the data-parallel hook (collectives are not captured).
+    Temperature is fixed at capture time.  Not available together with the data-parallel hook
+    (collectives are not captured).
+
+    The envelope is deliberately the one that is tested on the GPU (and the one where launches, not
+    kernels, set the step time): a module in training mode that has not run yet, embedding_dim <= 64
+    (every kernel within the default 64 KiB of LDS), the fp32 search, and no eager forward of the same
+    module once it is captured.  Outside it the constructor refuses: replays of graphs captured from a
+    module that was also run eagerly, or in eval mode, ended in GPU memory faults on ROCm 7.0's
+    runtime whose cause was not found, and a replay at embedding_dim = 256 returned too early to have
+    run the search kernel.
     """
 
     def __init__(self, module, example: torch.Tensor, temperature: float = 1.0, warmup: int = 2):
@@ -28,6 +36,13 @@ class GraphedQuantizer:
             raise RuntimeError("GraphedQuantizer needs a GPU tensor")
         if module._stats_reduce is not None:
             raise RuntimeError("the data-parallel hook cannot be captured into a graph")
+        if not module.training:
+            raise RuntimeError("GraphedQuantizer captures the training step only (see the class text)")
+        if module._ws is not None:
+            raise RuntimeError("GraphedQuantizer needs a module that has not run yet: capture it before any forward")
+        if module.embedding_dim > 64 or module.search_mode != "fp32":
+            raise RuntimeError("GraphedQuantizer is limited to embedding_dim <= 64 with the fp32 search: the "
+                               "launch-bound shapes it is meant and tested for")
         self.module = module
         self.training = module.training
         self.temperature = float(temperature)
@@ -49,6 +64,7 @@ class GraphedQuantizer:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph), torch.no_grad():
             self._out = module._run_step(self.static_in, self.temperature)
+        module._captured = True     # the module's own forward refuses from now on
 
     def __call__(self, z: torch.Tensor):
         if z.shape != self.static_in.shape:
