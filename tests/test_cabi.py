@@ -194,3 +194,41 @@ def test_filtered_entry_argument_checks():
     assert lib.vq_filter_work_bytes(1000) == (168 + 32 * 8) * 1000 and lib.vq_filter_work_bytes(65536) == (168 + 32 * 2) * 65536
     assert lib.vq_filter_image_bytes(8192, 256) == 256 * 17 * 1024 + 256 + 8192 * 32 + 256 * 4 * 33
     assert lib.vq_filter_loss_partial_bytes(1 << 20) > lib.vq_loss_partial_bytes(1 << 20)
+
+
+def test_boundary_module_host_side():
+    """QuantizerBoundary: constructor check of vqvae/custom_vqgan.py:25-26, the reference's attribute
+    names, loading of a CustomVQGAN-style state dict, refusal of CPU tensors."""
+    import torch
+    from vq_vae_amd import QuantizerBoundary
+    with pytest.raises(ValueError):
+        QuantizerBoundary(latent_channels=32, n_embed=16, embed_dim=64)
+    b = QuantizerBoundary(latent_channels=8, n_embed=16, embed_dim=8, ema_decay=0.9, commitment_loss_beta=2.0)
+    assert isinstance(b.quant_conv, torch.nn.Conv2d) and b.quant_conv.kernel_size == (1, 1)
+    assert isinstance(b.post_quant_conv, torch.nn.Conv2d) and b.post_quant_conv.out_channels == 8
+    assert b.quantize.num_embeddings == 16 and b.quantize.decay == 0.9 and b.quantize.commitment_cost == 2.0
+    assert b.config == {"num_vq_embeddings": 16, "vq_embed_dim": 8, "ema_decay": 0.9, "commitment_loss_beta": 2.0}
+    names = set(b.state_dict())
+    assert {"quant_conv.weight", "quant_conv.bias", "post_quant_conv.weight", "post_quant_conv.bias",
+            "quantize.embedding.weight", "quantize.ema_w", "quantize.ema_cluster_size", "quantize.usage_count",
+            "quantize.last_reset_epoch", "quantize.last_low_usage_reset_epoch"} == names
+    sd = {k: torch.randn_like(v) for k, v in b.state_dict().items()}
+    sd["encoder.conv_in.weight"] = torch.zeros(3)
+    sd["decoder.conv_out.bias"] = torch.zeros(3)
+    b.load_vqgan_state_dict(sd)
+    for k, v in b.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    # the log-variance half of a 2x-channel encoder output is dropped before quant_conv (:66-67)
+    z = b.to_latents(torch.randn(2, 16, 4, 4))
+    assert z.shape == (2, 8, 4, 4)
+    with pytest.raises(RuntimeError):
+        b(torch.randn(2, 8, 4, 4))
+
+
+def test_graphed_quantizer_refuses_cpu_and_unsupported_modules():
+    import torch
+    from vq_vae_amd import EMAVectorQuantizer
+    from vq_vae_amd.graph import GraphedQuantizer
+    m = EMAVectorQuantizer(16, 8, 1.0)
+    with pytest.raises(RuntimeError):
+        GraphedQuantizer(m, torch.zeros(1, 8, 2, 2))
