@@ -6,10 +6,10 @@
 // The N x K distance matrix and the N x K one-hot matrix never exist in memory.
 //
 // Design (z-stationary, MFMA-bound):
-//   * A workgroup of 4 waves owns 256 rows of z.  Each wave keeps its 64 rows (two 32-row
-//     MFMA column tiles) in registers for the whole sweep -- the 512 KiB register file of
-//     a CU is the largest on-chip store, so z is read from HBM exactly once and never
-//     touches LDS.
+//   * A workgroup of 8 waves owns 256 rows of z.  Each wave keeps its 32 rows (one 32-row
+//     MFMA column tile; a template parameter allows 4 waves with two tiles each) in registers
+//     for the whole sweep -- the 512 KiB register file of a CU is the largest on-chip store,
+//     so z is read from HBM exactly once and never touches LDS.
 //   * The codebook streams through LDS in stages of 64 codes.  vq_codebook_prep stores it
 //     in "image" order, i.e. exactly the bytes a wave's lanes want for the A operand of
 //     v_mfma_f32_32x32x2_f32, so a stage is a linear 65 KiB global->LDS DMA copy
@@ -21,8 +21,8 @@
 //     cross-half exchange at the very end.
 //   * fp32 MFMA is bit-for-bit an fmaf chain over the channels in increasing order, which
 //     is what the CPU oracle computes; indices are therefore compared bit-exactly.
-//   * The scan of a finished 32x64 accumulator pair runs while the MFMAs of the next pair
-//     are in flight (two accumulator sets alternate).
+//   * The scan of a finished accumulator tile runs while the MFMAs of the next one are in
+//     flight (two accumulator sets alternate), and the SIMD's second wave fills what is left.
 #include "vq_common.h"
 
 namespace {
