@@ -108,6 +108,11 @@ int vq_search(const float* z, int layout, int64_t N, int D, int64_t HW, const fl
  */
 size_t vq_filter_image_bytes(int K, int D);
 size_t vq_filter_work_bytes(int64_t N);
+/* How a filter pass over `rows` rows divides its codebook sweep when it has too few row workgroups
+ * to fill the chip: parts[0] = parts of the sweep, parts[1] = stages (128 codes) per part.  Host
+ * code only; the work buffer of vq_filter_work_bytes(N) holds the key lists of every part of the
+ * first pass (rows = N) and of the second pass (rows <= N/8). */
+int vq_filter_split(int64_t rows, int K, int* parts);
 int vq_filter_prep(const float* E, const float* e2, int K, int D, void* fimage, void* stream);
 size_t vq_filter_loss_partial_bytes(int64_t N);
 int vq_search_filtered(const float* z, int layout, int64_t N, int D, int64_t HW, const float* E, const float* image,

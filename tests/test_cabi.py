@@ -232,3 +232,41 @@ def test_graphed_quantizer_refuses_cpu_and_unsupported_modules():
     m = EMAVectorQuantizer(16, 8, 1.0)
     with pytest.raises(RuntimeError):
         GraphedQuantizer(m, torch.zeros(1, 8, 2, 2))
+
+
+def test_filter_sweep_split_fits_the_work_buffer():
+    """The divided sweep of the filtered search (host-side rule, no GPU): every part gets at least one
+    stage, the first pass's per-part key lists fit behind the fixed regions of the work buffer, and
+    the second pass (at most N/8 rows) never holds more than N (row, part) lists."""
+    from vq_vae_amd import _lib
+    lib = _lib.load()
+    parts = (ctypes.c_int * 2)()
+
+    def split(rows, K):
+        assert lib.vq_filter_split(rows, K, parts) == 0
+        return parts[0], parts[1]
+
+    rng = np.random.default_rng(5)
+    Ns = [1, 2, 31, 512, 513, 4096, 4999, 16384, 65536, 98303, 98304, 98305, 131072, 1 << 20, 1 << 22]
+    Ns += [int(x) for x in rng.integers(1, 1 << 22, 40)]
+    for N in Ns:
+        NP = (N + 3) // 4 * 4
+        work = lib.vq_filter_work_bytes(N)
+        for K in (1, 100, 128, 129, 512, 1000, 2048, 8192):
+            stages = (K + 127) // 128
+            S, sps = split(N, K)
+            assert 1 <= S <= 8 and sps >= 1 and S * sps >= stages and (S - 1) * sps < stages
+            if stages >= 2:
+                assert sps >= 2 or S == 1 or stages < 2 * S          # at least two stages per part where possible
+            wgs = (N + 511) // 512
+            assert S == 1 or S * wgs <= 256                            # parts only while the chip is not full
+            if S > 1:
+                assert 168 * NP + 32 * NP * S <= work                  # first pass: lists of every part
+            else:
+                assert 168 * NP <= work
+            for count in {0, 1, 511, 512, 513, N // 16, N // 8}:
+                if count > N // 8:
+                    continue
+                S2, _ = split(count, K)
+                assert count * S2 * 64 <= NP * 64                      # second pass: within its N x 64 byte region
+                assert count * 64 <= NP * 8 and count * 32 <= NP * 4   # folded lists and row terms

@@ -33,6 +33,7 @@ SIGNATURES = {
                           c_void_p]),
     "vq_filter_image_bytes": (c_size_t, [c_int, c_int]),
     "vq_filter_work_bytes": (c_size_t, [c_int64]),
+    "vq_filter_split": (c_int, [c_int64, c_int, c_void_p]),
     "vq_filter_prep": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "vq_filter_loss_partial_bytes": (c_size_t, [c_int64]),
     "vq_search_filtered": (c_int, [c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,

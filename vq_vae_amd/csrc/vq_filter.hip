@@ -737,6 +737,19 @@ int vq_filter_prep(const float* E, const float* e2, int K, int D, void* fimage, 
 // Work buffer: [keys of pass 1: N x 32][row terms: N x 32][list A: N x 4][keys of pass 2: N x 64][row terms: N x 32][list B: N x 4]
 // (regions laid out for N rounded up to a multiple of 4, which keeps each 16-byte aligned), then, for
 // batches small enough that the first pass divides its sweep, the S key lists per row of that pass.
+// How a filter pass over `rows` rows of a codebook of K codes divides its sweep: parts[0] = number of
+// parts (blockIdx.y), parts[1] = stages of 128 codes per part.  Host-side view of fq_split, exported
+// so that the layout rules (every part non-empty, rows x parts within the work buffer) can be
+// checked without a GPU.
+int vq_filter_split(int64_t rows, int K, int* parts) {
+  if (rows < 0 || K <= 0 || !parts) return VQ_ERR_INVALID_ARG;
+  int S, sps;
+  fq_split((rows + FQ_WG_ROWS - 1) / FQ_WG_ROWS, fq_tiles(K) / FQ_STAGE_TILES, S, sps);
+  parts[0] = S;
+  parts[1] = sps;
+  return VQ_OK;
+}
+
 size_t vq_filter_work_bytes(int64_t N) {
   return N > 0 ? (size_t)((N + 3) & ~(int64_t)3) * 168 + fq_split_extra_bytes(N) : 256;
 }
