@@ -1,6 +1,6 @@
 """Fuzz of the filtered search against the fp32 search: random shapes, scales, structures and temperatures;
 every index, winning distance and output value must be bit-identical.  python tools/fuzz_filtered.py [seed] [trials]"""
-import sys, os, time, torch, numpy as np
+import sys, os, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vq_vae_amd import ops
 dev = torch.device('cuda:0'); ws = ops.Workspace(dev)

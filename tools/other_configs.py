@@ -1,4 +1,4 @@
-import sys, os, time, torch, numpy as np
+import sys, os, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vq_vae_amd import ops, stats, EMAVectorQuantizer
 dev = torch.device('cuda:0'); ws = ops.Workspace(dev)

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 #: the library built in-tree; VQ_VAE_AMD_LIB selects another build of the same ABI (kernel experiments)

@@ -11,8 +11,6 @@ from __future__ import annotations
 
 import torch
 
-from . import ops
-
 
 class GraphedQuantizer:
     """Captured ``EMAVectorQuantizer`` step for inputs of ``example``'s shape.
