@@ -211,7 +211,8 @@ def main() -> None:
     out = step(False)
     torch.cuda.synchronize()
 
-    search_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_pairs]))
+    search_all = [a.elapsed_time(b) for a, b in ev_pairs]
+    search_ms = float(np.mean(search_all))
     flops = 2.0 * rows * K * D                       # algorithmic: one N x K x D contraction per step
     achieved = flops / (search_ms * 1e-3) / 1e12
     # sanity of the last step's outputs (cheap; outside the timed region)
@@ -267,6 +268,7 @@ def main() -> None:
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "traffic": measured_traffic(rows), "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
                          "algorithmic_hbm_bytes": rows * (2 * D * 4 + 12), "ms_per_launch": search_ms,
+                         "ms_per_launch_median": float(np.median(search_all)), "ms_per_launch_min": float(np.min(search_all)),
                          "flops_per_launch": flops},
             "perplexity": float(out.perplexity.item()),
         }
