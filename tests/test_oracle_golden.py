@@ -185,3 +185,19 @@ def test_boundary_convs_around_the_quantizer(mode):
     assert rel_err(st.embedding, g["state_embedding_weight"]) <= TOL
     assert rel_err(st.ema_w, g["state_ema_w"]) <= TOL
     assert rel_err(st.ema_cluster_size, g["state_ema_cluster_size"]) <= TOL
+
+
+def test_oracle_is_clean_under_address_and_ub_sanitizers(tmp_path):
+    """oracle/asan_check.c: every oracle entry point over awkward sizes, built with
+    -fsanitize=address,undefined (host code only)."""
+    import shutil
+    import subprocess
+    odir = os.path.join(os.path.dirname(GOLDEN), "..", "oracle")
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    build = subprocess.run(["make", "-s", "-C", odir, "asan_check"], capture_output=True, text=True)
+    if build.returncode != 0:
+        pytest.skip("sanitizer runtime not available: " + build.stderr[-200:])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:verify_asan_link_order=0", OMP_NUM_THREADS="4")
+    run = subprocess.run([os.path.join(odir, "asan_check")], capture_output=True, text=True, env=env, timeout=300)
+    assert run.returncode == 0 and "asan_check ok" in run.stdout, run.stderr[-2000:]
