@@ -1,6 +1,11 @@
-"""HIP-graph replay of the training step (GraphedQuantizer).  Collected after the other GPU tests on
-purpose: graphs are the one part of the package whose behaviour outside the tested envelope is not
-understood (see vq_vae_amd/graph.py), so nothing else should depend on this file's outcome."""
+"""HIP-graph replay of the training step (GraphedQuantizer).
+
+Not collected by a plain `pytest tests` (the file name does not start with test_): run it by name,
+    python -m pytest tests/wip_gpu_graph.py -m gpu
+It has passed in every run so far (fresh module, training mode, K=512, D=64, 204 replays), but graph
+replays outside that scenario ended in GPU memory faults whose cause is not understood (see
+vq_vae_amd/graph.py), and a fault takes the whole test process -- and the box -- with it.  Until the
+cause is found nothing else should depend on this file's outcome."""
 import time
 
 import numpy as np
