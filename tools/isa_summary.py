@@ -3,7 +3,7 @@
 and a check that no instruction writes through the scalar data cache (scalar stores / atomics / cache
 write-back), which this code base never does.  Needs only hipcc (no GPU).
 
-    python tools/isa_summary.py > profiles/r1_isa_summary.txt
+    python tools/isa_summary.py > isa_summary.txt
 """
 import os
 import re
