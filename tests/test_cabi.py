@@ -270,3 +270,23 @@ def test_filter_sweep_split_fits_the_work_buffer():
                 S2, _ = split(count, K)
                 assert count * S2 * 64 <= NP * 64                      # second pass: within its N x 64 byte region
                 assert count * 64 <= NP * 8 and count * 32 <= NP * 4   # folded lists and row terms
+
+
+def test_header_and_library_from_plain_c(tmp_path):
+    """include/vq_hip.h compiles as C99 (-pedantic -Werror) and libvqhip.so links and runs from a C
+    program that calls the host-only entry points (tests/cabi/link_check.c)."""
+    import shutil
+    import subprocess
+    from vq_vae_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    _lib.load()
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = str(tmp_path / "link_check")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "cabi", "link_check.c"), "-L", libdir, "-lvqhip",
+           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    build = subprocess.run(cmd, capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and "link_check ok" in run.stdout, run.stdout + run.stderr
