@@ -244,6 +244,35 @@ def main() -> None:
         except Exception as exc:  # the extra must never cost the headline line
             filt = {"error": f"{type(exc).__name__}: {exc}"}
 
+    # the same step at the size of one GPU's share of a training batch (64 images -> 64 Ki latents): not
+    # the headline workload, reported for orientation only
+    def small_batch_extra(rows_small: int = 65536) -> dict:
+        zs = z[: rows_small // (H * W)].contiguous()
+        res = {"rows": rows_small}
+        for name, filt in (("fp32_ms_per_step", False), ("filtered_ms_per_step", True)):
+            Es = E0.clone(); ws_s = ops.Workspace(dev)
+            w_s = torch.zeros(K, D, device=dev); c_s = torch.zeros(K, device=dev); u_s = torch.zeros(K, device=dev)
+
+            def one():
+                ops.quantize_step(zs, Es, w_s, c_s, u_s, beta=BETA, decay=DECAY, epsilon=EPS, temperature=1.0,
+                                  training=True, ws=ws_s, filtered=filt)
+            for _ in range(3):
+                one()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                one()
+            torch.cuda.synchronize()
+            res[name] = (time.perf_counter() - t0) / 20 * 1e3
+        return res
+
+    small = None
+    if world == 1 and not args.no_filtered and rows >= 65536:
+        try:
+            small = small_batch_extra()
+        except Exception as exc:
+            small = {"error": f"{type(exc).__name__}: {exc}"}
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         line = {
@@ -274,6 +303,8 @@ def main() -> None:
         }
         if filt is not None:
             line["filtered_search"] = filt
+        if small is not None:
+            line["per_gpu_training_batch"] = small
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             try:
