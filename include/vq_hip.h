@@ -28,6 +28,7 @@ enum {
   VQ_OK = 0,
   VQ_ERR_INVALID_ARG = 1,   /* null pointer, non-positive size, misaligned buffer          */
   VQ_ERR_UNSUPPORTED = 2,   /* shape outside what the kernels handle (D > 4096, ...)       */
+  VQ_ERR_TOO_LARGE = 3,     /* size beyond the fixed maximum of an entry point without scratch */
   VQ_ERR_HIP_BASE = 1000    /* + hipError_t                                                */
 };
 
@@ -271,6 +272,19 @@ int vq_index_stats(const uint32_t* counts, int K, int64_t M, double* out64, floa
 int vq_pairwise_stats(const float* E, const float* image, const float* e2, int K, int D, float* nn_dist,
                       int64_t* nn_idx, double* sum_partial, float* mm_partial, double* out, int32_t* control,
                       void* stream);
+
+/*
+ * vq_pairwise_stats for callers that cannot allocate device memory (code under HIP graph capture,
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same kernels
+ * and same results as vq_pairwise_stats, but sum_partial / mm_partial live in a device array inside
+ * the library (about 262 KiB per GPU, held until the process ends) instead of caller memory; the
+ * call allocates and frees nothing.  K is limited to VQ_PAIRWISE_STATIC_MAX_K (VQ_ERR_TOO_LARGE
+ * beyond it).  All calls on one GPU share that array: calls that overlap on one GPU (two streams,
+ * two threads) race; calls in stream order do not, and nothing has to be cleared between them.
+ */
+#define VQ_PAIRWISE_STATIC_MAX_K 65536
+int vq_pairwise_stats_static(const float* E, const float* image, const float* e2, int K, int D, float* nn_dist,
+                             int64_t* nn_idx, double* out, int32_t* control, void* stream);
 
 /*
  * Codebook-row-sharded search support: pack (distance, index) into one int64 whose

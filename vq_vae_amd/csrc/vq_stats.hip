@@ -222,6 +222,39 @@ int vq_pairwise_stats(const float* E, const float* image, const float* e2, int K
   return vq_hip_status(hipGetLastError());
 }
 
+// ---- vq_pairwise_stats without caller-provided scratch ------------------------------------
+// The partial sums, the min/max partials and the list of non-finite rows live in a file-scope
+// device array instead of caller memory.  Every GPU holds its own copy of the array at its own
+// address for the life of the process; the address is looked up once per device.
+#define VQ_PW_STATIC_BLOCKS ((VQ_PAIRWISE_STATIC_MAX_K + VQ_WG_ROWS - 1) / VQ_WG_ROWS)
+#define VQ_PW_STATIC_SUM_BYTES (((size_t)VQ_PW_STATIC_BLOCKS * 8 + 255) / 256 * 256)
+#define VQ_PW_STATIC_MM_BYTES ((2 * (size_t)VQ_PW_STATIC_BLOCKS + VQ_PAIRWISE_STATIC_MAX_K) * 4)
+static __device__ __align__(256) unsigned char vq_pw_scratch[VQ_PW_STATIC_SUM_BYTES + VQ_PW_STATIC_MM_BYTES];
+static void* vq_pw_scratch_ptr[64] = {};  // device address of vq_pw_scratch, per device ordinal
+
+int vq_pairwise_stats_static(const float* E, const float* image, const float* e2, int K, int D, float* nn_dist,
+                             int64_t* nn_idx, double* out, int32_t* control, void* stream) {
+  if (!E || !image || !e2 || !nn_dist || !nn_idx || !out || !control || K <= 0) return VQ_ERR_INVALID_ARG;
+  if (K > VQ_PAIRWISE_STATIC_MAX_K) return VQ_ERR_TOO_LARGE;
+  if (!vq_fast_dim(D)) return VQ_ERR_UNSUPPORTED;
+  int dev = 0;
+  VQ_CHECK_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return VQ_ERR_UNSUPPORTED;
+  if (vq_pw_scratch_ptr[dev] == nullptr) {
+    void* p = nullptr;
+    VQ_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(vq_pw_scratch)));
+    if (p == nullptr) return VQ_ERR_HIP_BASE + (int)hipErrorInvalidSymbol;
+    vq_pw_scratch_ptr[dev] = p;
+  }
+  // Nothing in the array has to start at zero: every workgroup of the sweep overwrites its own
+  // partials, the finish kernel reads exactly those, and the row list is indexed by a counter in
+  // `control`, which the caller resets.
+  unsigned char* base = static_cast<unsigned char*>(vq_pw_scratch_ptr[dev]);
+  double* sum_partial = reinterpret_cast<double*>(base);
+  float* mm_partial = reinterpret_cast<float*>(base + VQ_PW_STATIC_SUM_BYTES);
+  return vq_pairwise_stats(E, image, e2, K, D, nn_dist, nn_idx, sum_partial, mm_partial, out, control, stream);
+}
+
 int vq_pack_dist_index(const float* dmin, const int64_t* idx64, int64_t N, int64_t* packed, void* stream) {
   if (!dmin || !idx64 || !packed || N <= 0) return VQ_ERR_INVALID_ARG;
   hipLaunchKernelGGL(vq_pack_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dmin, idx64,
@@ -244,12 +277,13 @@ int vq_unpack_dist_index(const int64_t* packed, int64_t N, float* dmin, int64_t*
   return vq_hip_status(hipGetLastError());
 }
 
-int vq_version(void) { return 110; }
+int vq_version(void) { return 120; }
 
 const char* vq_status_string(int status) {
   if (status == VQ_OK) return "ok";
   if (status == VQ_ERR_INVALID_ARG) return "invalid argument";
   if (status == VQ_ERR_UNSUPPORTED) return "unsupported shape";
+  if (status == VQ_ERR_TOO_LARGE) return "size beyond the fixed maximum of this entry point";
   if (status >= VQ_ERR_HIP_BASE) return hipGetErrorString((hipError_t)(status - VQ_ERR_HIP_BASE));
   return "unknown status";
 }
