@@ -35,9 +35,36 @@ BETA, DECAY, EPS = 3.0, 0.95, 1e-5
 PEAK_FP32_MFMA_TFLOPS = 157.3   # dense fp32 matrix peak of MI355X (256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz)
 
 
-def cpu_baseline(rows: int = 16384, reps: int = 3) -> dict:
+def host_cpu() -> dict:
+    """Model name, logical and physical core counts of the host, from /proc/cpuinfo."""
+    model, cores, logical = "unknown", set(), 0
+    try:
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                key, _, val = ln.partition(":")
+                key, val = key.strip(), val.strip()
+                if key == "model name":
+                    model = val
+                elif key == "processor":
+                    logical += 1
+                elif key == "physical id":
+                    phys = val
+                elif key == "core id":
+                    core = val
+                elif not key and phys is not None:
+                    cores.add((phys, core)); phys = core = None
+    except OSError:
+        pass
+    return {"model": model, "logical_cpus": logical or (os.cpu_count() or 1), "physical_cores": len(cores) or None}
+
+
+def cpu_baseline(rows: int = 16384, reps: int = 10) -> dict:
     """The reference's dense formulation (oracle/dense_port.py) on the host cores.
-    Sample: `rows` latent vectors (N x K fp32 matrices must fit host memory), `reps` steps."""
+    Sample: `rows` latent vectors per step (the N x K fp32 matrices must fit host memory), `reps` timed
+    steps after one warm-up.  The cost of the formulation is linear in the number of rows (three
+    N x K x D products and N x K elementwise passes), so vectors/s at the sample size is the rate
+    the full 4 Mi-row batch would run at, chunk after chunk."""
     from oracle.dense_port import dense_forward, new_state
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
     torch.set_num_threads(threads)
@@ -51,10 +78,17 @@ def cpu_baseline(rows: int = 16384, reps: int = 3) -> dict:
         t0 = time.perf_counter()
         dense_forward(z, st, BETA, DECAY, EPS, 1.0, True)
         times.append(time.perf_counter() - t0)
-    med = float(np.median(times))
+    med, best = float(np.median(times)), float(np.min(times))
+    cpu = host_cpu()
     return {"value": rows / med, "unit": "vectors/s", "cores": threads, "kind": "port",
+            "value_best": rows / best, "cpu_model": cpu["model"], "host_logical_cpus": cpu["logical_cpus"],
+            "host_physical_cores": cpu["physical_cores"], "reps": reps,
+            "seconds_per_step_median": med, "seconds_per_step_min": best,
             "sample": f"dense one-hot PyTorch formulation of the reference forward+EMA, K={K} D={D}, "
-                      f"{rows} vectors/step, median of {reps} steps ({med:.3f} s/step), torch {torch.__version__} CPU"}
+                      f"{rows} vectors/step, {reps} steps after 1 warm-up, value = rows / median step time "
+                      f"({med:.3f} s; min {best:.3f} s), {threads} torch threads, torch {torch.__version__} CPU; "
+                      f"cost is linear in the rows, so the rate holds for the 4 Mi-row batch processed in chunks "
+                      f"of this size ({4 * 1024 * 1024 / rows * med:.0f} s extrapolated)"}
 
 
 def parity_gate(z: torch.Tensor, E0: torch.Tensor, rows: int = 16384) -> dict:
@@ -94,20 +128,43 @@ def parity_gate(z: torch.Tensor, E0: torch.Tensor, rows: int = 16384) -> dict:
 
 def measured_traffic(rows: int):
     """HBM bytes per launch of the search kernel from the committed rocprofv3 PMC passes
-    (profiles/r1_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction), when the
-    profile was taken on this workload; None otherwise.  bench.py cannot collect PMC counters itself."""
+    (profiles/r*_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction).  bench.py cannot
+    collect PMC counters itself, so the figure is only quoted when the profile was taken on this workload
+    AND on this build of the kernel (SHA-256 of vq_search.hip recorded in the profile); None otherwise."""
+    import glob
+    import hashlib
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
-            prof = json.load(f)
-        w = prof["workload"]
-        if (w["K"], w["D"], w["rows"]) != (K, D, rows):
-            return None
-        for k in prof["kernels"]:
-            if k["kernel"].startswith("vq_search_mfma_kernel"):
-                return float(k["hbm_bytes_corrected"])
-    except (OSError, KeyError, ValueError):
-        pass
-    return None
+        with open(os.path.join(ROOT, "vq_vae_amd", "csrc", "vq_search.hip"), "rb") as f:
+            sha = hashlib.sha256(f.read()).hexdigest()
+    except OSError:
+        return None, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                prof = json.load(f)
+            w = prof["workload"]
+            if (w["K"], w["D"], w["rows"]) != (K, D, rows):
+                continue
+            if prof.get("source_sha256", {}).get("vq_vae_amd/csrc/vq_search.hip") != sha:
+                continue
+            for k in prof["kernels"]:
+                if k["kernel"].startswith("vq_search_mfma_kernel"):
+                    return float(k["hbm_bytes_corrected"]), os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
+def launch_ranks(n: int) -> int:
+    """Start `n` ranks of this script under torch.distributed.run on this node and wait for them."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd)
 
 
 def main() -> None:
@@ -130,12 +187,17 @@ def main() -> None:
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["BENCH_WATCHDOG"]), exit=True)
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Called directly with N > 1: this process has not touched the GPU yet, so it starts the N ranks as
+        # fresh children (one per GPU), relays their output (rank 0 prints the JSON line) and exits with
+        # their status.
+        raise SystemExit(launch_ranks(args.gpus))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
     if args.backend != "nccl":
         local_rank %= max(1, torch.cuda.device_count())     # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local_rank)
@@ -274,12 +336,15 @@ def main() -> None:
             small = {"error": f"{type(exc).__name__}: {exc}"}
 
     if rank == 0:
+        traffic, traffic_src = measured_traffic(rows)
         ms_per_step = elapsed / args.steps * 1e3
         line = {
             "metric": "quantized latent vectors/sec (argmin+EMA update), K=8192 D=256",
             "value": rows * world * args.steps / elapsed,
             "unit": "vectors/s",
             "n_gpus": world,
+            "world_size": dist.get_world_size() if world > 1 else 1,
+            "backend": (dist.get_backend() if world > 1 else None),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
@@ -295,7 +360,7 @@ def main() -> None:
                        "rows_per_gpu": rows, "parallelism": f"dp{world}" if world > 1 else "single"},
             "roofline": {"bound": "mfma", "kernel": "vq_search_mfma_kernel<256,NCHW>", "achieved": achieved,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                         "traffic": measured_traffic(rows), "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
+                         "traffic": traffic, "traffic_unit": "bytes/launch (rocprofv3 PMC)", "traffic_source": traffic_src,
                          "algorithmic_hbm_bytes": rows * (2 * D * 4 + 12), "ms_per_launch": search_ms,
                          "ms_per_launch_median": float(np.median(search_all)), "ms_per_launch_min": float(np.min(search_all)),
                          "flops_per_launch": flops},

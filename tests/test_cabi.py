@@ -225,15 +225,6 @@ def test_boundary_module_host_side():
         b(torch.randn(2, 8, 4, 4))
 
 
-def test_graphed_quantizer_refuses_cpu_and_unsupported_modules():
-    import torch
-    from vq_vae_amd import EMAVectorQuantizer
-    from vq_vae_amd.graph import GraphedQuantizer
-    m = EMAVectorQuantizer(16, 8, 1.0)
-    with pytest.raises(RuntimeError):
-        GraphedQuantizer(m, torch.zeros(1, 8, 2, 2))
-
-
 def test_filter_sweep_split_fits_the_work_buffer():
     """The divided sweep of the filtered search (host-side rule, no GPU): every part gets at least one
     stage, the first pass's per-part key lists fit behind the fixed regions of the work buffer, and

@@ -179,9 +179,6 @@ class EMAVectorQuantizer(nn.Module):
             raise RuntimeError(f"shape '[-1, {self.embedding_dim}]' is invalid for input of size "
                                f"{tuple(inputs.shape)}: expected (B, {self.embedding_dim}, H, W)")
         load()  # fail loudly here when libvqhip.so is missing
-        if getattr(self, "_captured", False):
-            raise RuntimeError("this module's step is captured in a HIP graph (GraphedQuantizer): call the graph, "
-                               "not the module")
         self._follow(inputs.device)
         z = inputs
         if z.dtype != torch.float32:
