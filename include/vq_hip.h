@@ -274,6 +274,19 @@ int vq_pairwise_stats(const float* E, const float* image, const float* e2, int K
                       void* stream);
 
 /*
+ * The same sweep for a range of rows: rows [row_base, row_base + n_rows) of the codebook against all
+ * K codes -- one rank's share when the K x K sweep is sharded by rows over several GPUs (the
+ * reference has no multi-device code; the analysis is the one README.md:26-29 describes).
+ * nn_dist / nn_idx get n_rows entries (nn_idx holds global code numbers); out[3] (double): min, SUM
+ * (not mean) and max over the pairs (i, j), i in the range, j != i, so that ranks combine them with
+ * MIN / SUM / MAX.  sum_partial: vq_search_blocks(n_rows) doubles; mm_partial:
+ * 2*vq_search_blocks(n_rows) + n_rows words.
+ */
+int vq_pairwise_rows(const float* E, const float* image, const float* e2, int K, int D, int64_t row_base,
+                     int64_t n_rows, float* nn_dist, int64_t* nn_idx, double* sum_partial, float* mm_partial,
+                     double* out, int32_t* control, void* stream);
+
+/*
  * vq_pairwise_stats for callers that cannot allocate device memory (code under HIP graph capture,
  * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same kernels
  * and same results as vq_pairwise_stats, but sum_partial / mm_partial live in a device array inside

@@ -146,3 +146,66 @@ def test_shard_rows_cover_the_codebook():
         spans = [shard_rows(K, r, world) for r in range(world)]
         assert spans[0][0] == 0 and spans[-1][1] == K
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def _stats_worker(rank, world, port, K, D, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vq_vae_amd.distributed import all_reduce_counts, merge_pairwise_shards, shard_rows
+    # (1) the index stream sharded over the ranks: each rank counts its share
+    rng = np.random.default_rng(77)
+    allidx = rng.zipf(1.3, 50_000) % K
+    mine = np.array_split(allidx, world)[rank]
+    c = np.bincount(mine, minlength=K).astype(np.uint32)
+    if rank == 0:
+        c[5] = np.uint32(3_000_000_000)                      # above 2^31: the int32 carrier must not lose it
+    counts, total = all_reduce_counts(torch.from_numpy(c.view(np.int32).copy()), mine.size)
+    # (2) the K x K pairwise sweep sharded by rows
+    E = gauss(31, (K, D))
+    E[K - 3] = E[4]                                          # duplicate codes: distance 0, lowest index wins
+    lo, hi = shard_rows(K, rank, world)
+    nn_dist, nn_idx, _ = vo.pairwise(E)
+    Ed = E.astype(np.float64)
+    P = ((Ed[lo:hi, None, :] - Ed[None, :, :]) ** 2).sum(-1)
+    P[np.arange(hi - lo), np.arange(lo, hi)] = np.nan        # the pair (i, i) is not counted
+    packed = np.full(K, np.iinfo(np.int64).max, np.int64)
+    packed[lo:hi] = pack_key(nn_dist[lo:hi], nn_idx[lo:hi])
+    scal = torch.tensor([np.nanmin(P), np.nansum(P), np.nanmax(P)], dtype=torch.float64)
+    merged, mn, tot, mx = merge_pairwise_shards(torch.from_numpy(packed), scal)
+    q.put((rank, counts.numpy().view(np.uint32).astype(np.int64), total, unpack_index(merged.numpy()), mn, tot, mx))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_statistics_over_gloo():
+    """Index statistics sharded over the stream (int64 SUM of the histograms) and the pairwise
+    codebook sweep sharded by rows (packed-key MIN + MIN/SUM/MAX of the scalars), world size 2."""
+    K, D, world = 96, 16, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_stats_worker, args=(r, world, port, K, D, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(77)
+    allidx = rng.zipf(1.3, 50_000) % K
+    want = np.bincount(allidx, minlength=K).astype(np.int64)
+    want[5] += 3_000_000_000 - np.bincount(np.array_split(allidx, world)[0], minlength=K)[5]
+    E = gauss(31, (K, D))
+    E[K - 3] = E[4]
+    _, nn_idx, _ = vo.pairwise(E)
+    Ed = E.astype(np.float64)
+    P = ((Ed[:, None, :] - Ed[None, :, :]) ** 2).sum(-1)
+    off = ~np.eye(K, dtype=bool)
+    for rank, counts, total, merged_idx, mn, tot, mx in res:
+        assert np.array_equal(counts, want)
+        assert total == allidx.size
+        assert np.array_equal(merged_idx, nn_idx)
+        assert merged_idx[K - 3] == 4 and merged_idx[4] == K - 3
+        assert mn == P[off].min() and mx == P[off].max()
+        assert abs(tot - P[off].sum()) <= 1e-12 * P[off].sum()

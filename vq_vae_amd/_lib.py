@@ -67,6 +67,8 @@ SIGNATURES = {
     "vq_index_stats": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
     "vq_pairwise_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p]),
+    "vq_pairwise_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vq_pairwise_stats_static": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p]),
     "vq_pack_dist_index": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),

@@ -80,8 +80,9 @@ static inline int vq_launch_absmax(const float* z, int64_t numel, int32_t* contr
 
 // Internal (not in the public header): the pairwise variant of the MFMA search, z := E.
 extern "C" int vq_pairwise_search_launch(const float* E, const float* image, const float* e2, int K, int D,
-                                         float* nn_dist, int64_t* nn_idx, int32_t* idx32, double* sum_partial,
-                                         float* mm_partial, int32_t* nf_rows, int32_t* control, void* stream);
+                                         int64_t row_base, int64_t n_rows, float* nn_dist, int64_t* nn_idx,
+                                         int32_t* idx32, double* sum_partial, float* mm_partial, int32_t* nf_rows,
+                                         int32_t* control, void* stream);
 
 // Internal (not in the public header): bf16 filter + exact verification (vq_filter.hip).
 bool vq_filter_supported(int K, int D);

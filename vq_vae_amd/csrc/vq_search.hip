@@ -48,6 +48,7 @@ struct SearchArgs {
   // pairwise mode (z := E): skip the pair (n, n); per-workgroup partials of sum/min/max
   double* pw_sum;
   float* pw_minmax;
+  int64_t pw_row_base;  // pairwise over a range of rows: row n of z is code pw_row_base + n
   // codebook split for small batches: blockIdx.y sweeps stages [y*sps, y*sps + sps) and leaves
   // its per-row winner in part_d / part_i [ksplit][N]; a merge kernel picks the overall winner
   int ksplit;
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(512 / CT, 2 / CT) void vq_search_mfma_kernel(Search
     pmin[ct] = __builtin_inff();
     pmax[ct] = -__builtin_inff();
     // pairwise: the row index is the code index; remove the 4*h part the scan leaves out
-    self_code[ct] = PAIRWISE ? (int)(row0 + 32 * ct + j) - 4 * h : -1;
+    self_code[ct] = PAIRWISE ? (int)(a.pw_row_base + row0 + 32 * ct + j) - 4 * h : -1;
   }
 
   // Accumulator set B (second 32 codes of a stage) is scanned one stage late, under the
@@ -1098,15 +1099,17 @@ int vq_gather_st(const float* z, int layout, int64_t N, int D, int64_t HW, const
   return vq_hip_status(hipGetLastError());
 }
 
-int vq_pairwise_search_launch(const float* E, const float* image, const float* e2, int K, int D, float* nn_dist,
-                              int64_t* nn_idx, int32_t* idx32, double* sum_partial, float* mm_partial,
-                              int32_t* nf_rows, int32_t* control, void* stream) {
-  // internal helper of vq_pairwise_stats (vq_stats.hip); not part of the public header
+int vq_pairwise_search_launch(const float* E, const float* image, const float* e2, int K, int D, int64_t row_base,
+                              int64_t n_rows, float* nn_dist, int64_t* nn_idx, int32_t* idx32, double* sum_partial,
+                              float* mm_partial, int32_t* nf_rows, int32_t* control, void* stream) {
+  // internal helper of vq_pairwise_stats / vq_pairwise_rows (vq_stats.hip); not part of the public header.
+  // Rows [row_base, row_base + n_rows) of the codebook play the latents, all K rows the codes.
   SearchArgs a{};
-  a.z = E; a.E = E; a.image = image; a.e2 = e2; a.N = K; a.HW = 1; a.K = K;
+  a.z = E + (size_t)row_base * D; a.E = E; a.image = image; a.e2 = e2; a.N = n_rows; a.HW = 1; a.K = K;
   a.nstages = vq_kpad(K) / VQ_STAGE_CODES; a.T = 1.0f; a.code_base = 0;
   a.idx64 = nn_idx; a.idx32 = idx32; a.dmin = nn_dist; a.q_out = nullptr; a.loss_partial = nullptr;
   a.nf_rows = nf_rows; a.control = control; a.pw_sum = sum_partial; a.pw_minmax = mm_partial;
+  a.pw_row_base = row_base;
   a.ksplit = 1; a.stages_per_split = a.nstages;
   return run_mfma(a, D, false, false, true, (hipStream_t)stream);
 }

@@ -113,7 +113,8 @@ __global__ __launch_bounds__(1024) void vq_index_stats_kernel(const uint32_t* __
 
 __global__ __launch_bounds__(1024) void vq_pairwise_finish_kernel(const double* __restrict__ sum_partial,
                                                                   const float* __restrict__ mm_partial, int64_t nblocks,
-                                                                  int K, const int32_t* __restrict__ control,
+                                                                  int K, int want_mean,
+                                                                  const int32_t* __restrict__ control,
                                                                   double* __restrict__ out) {
   __shared__ double sh[1024];
   __shared__ float shmn[1024], shmx[1024];
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(1024) void vq_pairwise_finish_kernel(const double* 
   }
   if (t == 0) {
     out[0] = (double)shmn[0];
-    out[1] = K > 1 ? tot / ((double)K * (double)(K - 1)) : 0.0;
+    out[1] = !want_mean ? tot : (K > 1 ? tot / ((double)K * (double)(K - 1)) : 0.0);
     out[2] = (double)shmx[0];
   }
 }
@@ -206,20 +207,35 @@ int vq_index_stats(const uint32_t* counts, int K, int64_t M, double* out64, floa
   return vq_hip_status(hipGetLastError());
 }
 
+static int pairwise_common(const float* E, const float* image, const float* e2, int K, int D, int64_t row_base,
+                           int64_t n_rows, float* nn_dist, int64_t* nn_idx, double* sum_partial, float* mm_partial,
+                           double* out, int want_mean, int32_t* control, void* stream) {
+  if (!E || !image || !e2 || !nn_dist || !nn_idx || !sum_partial || !mm_partial || !out || !control || K <= 0)
+    return VQ_ERR_INVALID_ARG;
+  if (row_base < 0 || n_rows <= 0 || row_base + n_rows > K) return VQ_ERR_INVALID_ARG;
+  if (!vq_fast_dim(D)) return VQ_ERR_UNSUPPORTED;
+  const int64_t blocks = vq_search_blocks(n_rows);
+  // rows with a non-finite norm are appended behind the min/max partials (scratch of n_rows ints)
+  int32_t* nf_rows = reinterpret_cast<int32_t*>(mm_partial + 2 * blocks);
+  int rc = vq_pairwise_search_launch(E, image, e2, K, D, row_base, n_rows, nn_dist, nn_idx, nullptr, sum_partial,
+                                     mm_partial, nf_rows, control, stream);
+  if (rc != VQ_OK) return rc;
+  hipLaunchKernelGGL(vq_pairwise_finish_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, sum_partial, mm_partial,
+                     blocks, K, want_mean, control, out);
+  return vq_hip_status(hipGetLastError());
+}
+
 int vq_pairwise_stats(const float* E, const float* image, const float* e2, int K, int D, float* nn_dist,
                       int64_t* nn_idx, double* sum_partial, float* mm_partial, double* out, int32_t* control,
                       void* stream) {
-  if (!E || !image || !e2 || !nn_dist || !nn_idx || !sum_partial || !mm_partial || !out || !control || K <= 0)
-    return VQ_ERR_INVALID_ARG;
-  if (!vq_fast_dim(D)) return VQ_ERR_UNSUPPORTED;
-  // rows with a non-finite norm are appended behind the min/max partials (scratch of K ints)
-  int32_t* nf_rows = reinterpret_cast<int32_t*>(mm_partial + 2 * vq_search_blocks(K));
-  int rc = vq_pairwise_search_launch(E, image, e2, K, D, nn_dist, nn_idx, nullptr, sum_partial, mm_partial, nf_rows,
-                                     control, stream);
-  if (rc != VQ_OK) return rc;
-  hipLaunchKernelGGL(vq_pairwise_finish_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, sum_partial, mm_partial,
-                     vq_search_blocks(K), K, control, out);
-  return vq_hip_status(hipGetLastError());
+  return pairwise_common(E, image, e2, K, D, 0, K, nn_dist, nn_idx, sum_partial, mm_partial, out, 1, control, stream);
+}
+
+int vq_pairwise_rows(const float* E, const float* image, const float* e2, int K, int D, int64_t row_base,
+                     int64_t n_rows, float* nn_dist, int64_t* nn_idx, double* sum_partial, float* mm_partial,
+                     double* out, int32_t* control, void* stream) {
+  return pairwise_common(E, image, e2, K, D, row_base, n_rows, nn_dist, nn_idx, sum_partial, mm_partial, out, 0,
+                         control, stream);
 }
 
 // ---- vq_pairwise_stats without caller-provided scratch ------------------------------------

@@ -62,6 +62,42 @@ def make_stats_reduce(group: Optional[dist.ProcessGroup] = None, uneven_rows: bo
     return reduce
 
 
+def all_reduce_counts(counts_i32: torch.Tensor, total: int, group: Optional[dist.ProcessGroup] = None):
+    """Statistics sharded over the index stream: every rank holds the histogram of its share
+    (uint32 bit patterns in an int32 tensor) and the number of indices it counted.  One int64 SUM
+    all-reduce of [counts ‖ total]; returns (counts in the same uint32-in-int32 form, total).
+    Raises if a summed bin no longer fits 32 bits (the statistics kernel reads uint32 bins)."""
+    buf = torch.cat([counts_to_int64(counts_i32),
+                     torch.tensor([int(total)], dtype=torch.int64, device=counts_i32.device)])
+    _all_reduce(buf, dist.ReduceOp.SUM, group)
+    counts64, n_total = buf[:-1], int(buf[-1].item())
+    if int(counts64.max().item()) >= 1 << 32:
+        raise OverflowError("a summed histogram bin exceeds 32 bits")
+    wrapped = torch.where(counts64 >= 1 << 31, counts64 - (1 << 32), counts64).to(torch.int32)
+    return wrapped.contiguous(), n_total
+
+
+def merge_pairwise_shards(packed_i64: torch.Tensor, scalars_f64: torch.Tensor,
+                          group: Optional[dist.ProcessGroup] = None):
+    """Merge of the row-sharded pairwise codebook sweep.  ``packed_i64`` [K]: packed (distance,
+    index) keys of the nearest other code for the rows this rank swept, INT64_MAX elsewhere -- one
+    MIN all-reduce fills every entry.  ``scalars_f64`` (min, sum, max) of this rank's pairs: one
+    all-gather, combined as MIN / SUM / MAX (NaN from any rank propagates).
+    Returns (packed, min, sum, max)."""
+    _all_reduce(packed_i64, dist.ReduceOp.MIN, group)
+    world = dist.get_world_size(group)
+    mine = scalars_f64.detach().to(torch.float64).reshape(3)
+    if mine.is_cuda and dist.get_backend(group) == "gloo":
+        mine = mine.cpu()
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine.contiguous(), group=group)
+    allv = torch.stack(parts).cpu()
+    mn, total, mx = allv[:, 0], allv[:, 1], allv[:, 2]
+    nan = bool(torch.isnan(allv).any())
+    f = float("nan")
+    return (packed_i64, f if nan else float(mn.min()), f if nan else float(total.sum()), f if nan else float(mx.max()))
+
+
 def shard_rows(K: int, rank: int, world: int):
     """Codebook-row sharding: rank r owns rows [lo, hi) of the K-row codebook."""
     per = (K + world - 1) // world

@@ -32,6 +32,15 @@ class CodeUsage:
         ops.histogram(indices, self.K, self.ws, out=self.counts, accumulate=True)
         self.total += indices.numel()
 
+    def all_reduce(self, group=None) -> None:
+        """Sum the histogram over the ranks of ``group`` (each rank has seen its own share of the
+        indices): one int64 SUM all-reduce of counts[K] and the number of indices
+        (vqvae/codebook_utilization_check.py:93-98 and vqvae/vqgan_trainer.py:594-612 over a
+        sharded index stream).  Afterwards ``result()`` reports the statistics of the whole stream
+        on every rank."""
+        from . import distributed as vd
+        self.counts, self.total = vd.all_reduce_counts(self.counts, self.total, group)
+
     def result(self) -> dict:
         lib = load()
         out = torch.empty(5, dtype=torch.float64, device=self.device)
@@ -79,26 +88,71 @@ def count_used_codes(latents: torch.Tensor, codebook: torch.Tensor, ws: Optional
     return int((counts != 0).sum().item())
 
 
-def pairwise_codebook_stats(codebook: torch.Tensor, ws: Optional[ops.Workspace] = None) -> dict:
+def pairwise_codebook_stats(codebook: torch.Tensor, ws: Optional[ops.Workspace] = None, group=None) -> dict:
     """Nearest-other-code distance per code and min / mean / max of all pairwise squared
     distances ||e_i - e_j||^2 (i != j), computed by the MFMA search engine with z := E; the
-    K x K matrix is never stored."""
+    K x K matrix is never stored.
+
+    With ``group`` (a torch.distributed process group of more than one rank, every rank holding the
+    same codebook) the K x K sweep is sharded by rows: each rank sweeps its rows against all K codes
+    (``vq_pairwise_rows``), the per-row nearest neighbours are merged by a MIN all-reduce of packed
+    (distance, index) keys over a K-entry buffer, the scalars by one small all-gather; every rank
+    returns the full result."""
     lib = load()
     E = ops._f32c(codebook, "codebook")
     K, D = E.shape
     ws = ws or ops.Workspace(E.device)
     image, e2, control = ops.prepare_codebook(E, ws)
-    blocks = lib.vq_search_blocks(K)
-    nn_dist = torch.empty(K, dtype=torch.float32, device=E.device)
-    nn_idx = torch.empty(K, dtype=torch.int64, device=E.device)
+    sharded = group is not None and torch.distributed.get_world_size(group) > 1
+    if not sharded:
+        blocks = lib.vq_search_blocks(K)
+        nn_dist = torch.empty(K, dtype=torch.float32, device=E.device)
+        nn_idx = torch.empty(K, dtype=torch.int64, device=E.device)
+        sum_partial = ws.get("pw_sum", blocks * 8, torch.float64)
+        mm_partial = ws.get("pw_mm", (2 * blocks + K) * 4, torch.float32)
+        out = torch.empty(3, dtype=torch.float64, device=E.device)
+        check(lib.vq_pairwise_stats(ops._ptr(E), ops._ptr(image), ops._ptr(e2), K, D, ops._ptr(nn_dist),
+                                    ops._ptr(nn_idx), ops._ptr(sum_partial), ops._ptr(mm_partial), ops._ptr(out),
+                                    ops._ptr(control), ops._stream(E.device)), "vq_pairwise_stats")
+        v = out.cpu().tolist()
+        return {"nn_dist": nn_dist, "nn_idx": nn_idx, "min": v[0], "mean": v[1], "max": v[2]}
+
+    from . import distributed as vd
+    rank, world = torch.distributed.get_rank(group), torch.distributed.get_world_size(group)
+    lo, hi = vd.shard_rows(K, rank, world)
+    packed = torch.full((K,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=E.device)
+    part = pairwise_rows(E, lo, hi - lo, ws, prepared=(image, e2, control))
+    if hi > lo:
+        packed[lo:hi] = ops.pack_dist_index(part["nn_dist"], part["nn_idx"])
+    packed, mn, total, mx = vd.merge_pairwise_shards(packed, part["scalars"], group)
+    nn_dist, nn_idx, _ = ops.unpack_dist_index(packed, ws)
+    return {"nn_dist": nn_dist, "nn_idx": nn_idx, "min": mn, "mean": total / (K * (K - 1)) if K > 1 else 0.0,
+            "max": mx}
+
+
+def pairwise_rows(codebook: torch.Tensor, row_base: int, n_rows: int, ws: ops.Workspace, prepared=None) -> dict:
+    """One rank's share of the row-sharded pairwise sweep: rows [row_base, row_base + n_rows) of the
+    codebook against all of it.  Returns nn_dist / nn_idx for those rows (global code numbers) and
+    ``scalars`` = float64 device tensor (min, sum, max) over the pairs (i in the range, j != i) --
+    (+inf, 0, -inf) for an empty range."""
+    lib = load()
+    E = ops._f32c(codebook, "codebook")
+    K, D = E.shape
+    image, e2, control = prepared if prepared is not None else ops.prepare_codebook(E, ws)
+    if n_rows <= 0:
+        return {"nn_dist": torch.empty(0, dtype=torch.float32, device=E.device),
+                "nn_idx": torch.empty(0, dtype=torch.int64, device=E.device),
+                "scalars": torch.tensor([float("inf"), 0.0, float("-inf")], dtype=torch.float64, device=E.device)}
+    blocks = lib.vq_search_blocks(n_rows)
+    nn_dist = torch.empty(n_rows, dtype=torch.float32, device=E.device)
+    nn_idx = torch.empty(n_rows, dtype=torch.int64, device=E.device)
     sum_partial = ws.get("pw_sum", blocks * 8, torch.float64)
-    mm_partial = ws.get("pw_mm", (2 * blocks + K) * 4, torch.float32)
+    mm_partial = ws.get("pw_mm", (2 * blocks + n_rows) * 4, torch.float32)
     out = torch.empty(3, dtype=torch.float64, device=E.device)
-    check(lib.vq_pairwise_stats(ops._ptr(E), ops._ptr(image), ops._ptr(e2), K, D, ops._ptr(nn_dist),
-                                ops._ptr(nn_idx), ops._ptr(sum_partial), ops._ptr(mm_partial), ops._ptr(out),
-                                ops._ptr(control), ops._stream(E.device)), "vq_pairwise_stats")
-    v = out.cpu().tolist()
-    return {"nn_dist": nn_dist, "nn_idx": nn_idx, "min": v[0], "mean": v[1], "max": v[2]}
+    check(lib.vq_pairwise_rows(ops._ptr(E), ops._ptr(image), ops._ptr(e2), K, D, row_base, n_rows, ops._ptr(nn_dist),
+                               ops._ptr(nn_idx), ops._ptr(sum_partial), ops._ptr(mm_partial), ops._ptr(out),
+                               ops._ptr(control), ops._stream(E.device)), "vq_pairwise_rows")
+    return {"nn_dist": nn_dist, "nn_idx": nn_idx, "scalars": out}
 
 
 @torch.no_grad()
