@@ -219,9 +219,40 @@ def g9():
                             grad_bp=post_quant_conv.bias.grad.numpy().copy(), **state_of(q))
 
 
+def g10():
+    """A checkpoint file in the layout VQGANTrainer.save_checkpoint writes for its light variant
+    (vqvae/vqgan_trainer.py:409-423, :442-445): the state_dict of a module tree named like CustomVQGAN's
+    (quant_conv, quantize = the reference quantizer after two training steps, post_quant_conv;
+    vqvae/custom_vqgan.py:36-51) under 'vqgan_state_dict', plus epoch, best_val_loss, codebook_stats and
+    model_config.  Beside it: a batch and the reference's eval-mode outputs after the two steps."""
+    K, D = 64, 16
+    E = gauss(1002, (K, D)) * np.float32(0.6)
+    q = make_ref(K, D, 3.0, 0.95, E)
+    q.train(True)
+    for step in range(2):
+        run_step(q, gauss(1010 + step, (2, D, 4, 4)), 1.0)
+    q.last_reset_epoch.fill_(3)
+    tree = torch.nn.Module()
+    tree.quant_conv = torch.nn.Conv2d(D, D, 1)
+    tree.quantize = q
+    tree.post_quant_conv = torch.nn.Conv2d(D, D, 1)
+    stats = q.get_codebook_stats()
+    ckpt = {"epoch": 7, "vqgan_state_dict": tree.state_dict(),
+            "discriminator_state_dict": {"main.0.weight": torch.zeros(2, 2)},
+            "best_val_loss": float(stats["normalized_entropy"]), "codebook_stats": [dict(stats, epoch=7)],
+            "model_config": {"vq_num_embed": q.num_embeddings, "vq_embed_dim": D}}
+    torch.save(ckpt, os.path.join(HERE, "g10_checkpoint_light.pt"))
+    q.eval()
+    z = gauss(1020, (2, D, 4, 4))
+    o = run_step(q, z, 1.0)
+    np.savez_compressed(os.path.join(HERE, "g10_after_load.npz"), z=z, **o, **state_of(q),
+                        stats=np.array([stats["active_size"], stats["utilization"], stats["entropy"],
+                                        stats["normalized_entropy"], stats["total_usage"]], np.float64))
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g6, g8, g9):
+    for fn in (g1, g2, g3, g4, g6, g8, g9, g10):
         if not only or fn.__name__ in only:
             fn()
     total = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))

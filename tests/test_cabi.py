@@ -281,3 +281,38 @@ def test_header_and_library_from_plain_c(tmp_path):
     assert build.returncode == 0, build.stderr[-2000:]
     run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0 and "link_check ok" in run.stdout, run.stdout + run.stderr
+
+
+def test_reference_layout_checkpoint_file_loads(tmp_path):
+    """A checkpoint file in the reference trainer's layout (tests/golden/g10_checkpoint_light.pt, written by
+    tests/golden/make_golden.py from the reference quantizer after two training steps) is read with
+    torch.load(weights_only=True), its six quantizer tensors load strictly into this module, and the
+    oracle run from that state reproduces the reference's eval forward stored beside it."""
+    import torch
+    from conftest import GOLDEN, rel_err
+    from oracle import vq_oracle as vo
+    from vq_vae_amd import EMAVectorQuantizer, checkpoint
+    ck = checkpoint.load_reference_checkpoint(os.path.join(GOLDEN, "g10_checkpoint_light.pt"))
+    g = np.load(os.path.join(GOLDEN, "g10_after_load.npz"))
+    assert (ck["num_embeddings"], ck["embedding_dim"]) == (64, 16) and ck["epoch"] == 7
+    assert ck["model_config"] == {"vq_num_embed": 64, "vq_embed_dim": 16}
+    assert set(ck["model_state"]) >= {"quant_conv.weight", "post_quant_conv.bias", "quantize.ema_w"}
+    m = EMAVectorQuantizer(ck["num_embeddings"], ck["embedding_dim"], 3.0)
+    m.load_state_dict(ck["quantizer_state"], strict=True)
+    for k, v in m.state_dict().items():
+        assert np.array_equal(v.numpy(), g["state_" + k.replace(".", "_")]), k
+    assert int(m.last_reset_epoch) == 3
+    st = vo.OracleState(embedding=m.embedding.weight.detach().numpy().copy(), ema_w=m.ema_w.numpy().copy(),
+                        ema_cluster_size=m.ema_cluster_size.numpy().copy(), usage_count=m.usage_count.numpy().copy())
+    out = vo.forward(g["z"], st, 3.0, 0.95, 1e-5, 1.0, False)
+    assert np.array_equal(out["indices"].reshape(-1), g["indices"].reshape(-1))
+    assert rel_err(out["quantized"], g["quantized"]) <= 1e-6 and abs(out["loss"] - g["loss"]) <= 1e-5 * g["loss"]
+    # and back: the light variant written here is read by the same loader
+    full_state = dict(ck["model_state"])
+    path = tmp_path / "resaved_best_light.pt"
+    torch.save(checkpoint.light_checkpoint(full_state, epoch=8, best_val_loss=0.5, codebook_stats=ck["codebook_stats"]),
+               str(path))
+    again = checkpoint.load_reference_checkpoint(str(path))
+    assert again["epoch"] == 8 and again["model_config"] == ck["model_config"]
+    for k in ck["quantizer_state"]:
+        assert torch.equal(again["quantizer_state"][k], ck["quantizer_state"][k])

@@ -140,6 +140,16 @@ def test_lazy_onehot_above_threshold(dev):
     assert flat.shape == (128 * K,) and float(flat.sum()) == 128
     assert torch.equal(torch.argmax(enc, dim=1), idx.view(-1))     # torch function protocol
     assert enc.flatten().cpu().numpy().shape == (128 * K,)         # codebook_utilization_check.py:79
+    # operators a dense tensor supports: indexing, len, iteration, arithmetic, comparison, matmul
+    q2, _, (_, idx2, lazy) = m(z)
+    assert isinstance(lazy, LazyOneHot) and lazy._dense is None
+    assert len(lazy) == 128 and int(torch.argmax(lazy[3])) == int(idx2[3]) and lazy._dense is None
+    dense = enc.materialize()
+    assert torch.equal(lazy[5:9, :], dense[5:9, :])
+    assert torch.equal(lazy + 1, dense + 1) and torch.equal(2.0 * lazy, dense * 2.0)
+    assert torch.equal(lazy @ m.embedding.weight, dense @ m.embedding.weight)
+    assert bool((lazy == dense).all()) and torch.equal(-lazy, -dense)
+    assert sum(1 for _ in lazy) == 128
 
 
 def test_half_and_noncontiguous_inputs(dev):
@@ -259,3 +269,24 @@ def test_channels_last_input_is_consumed_without_copy(dev):
     (q0.sum() * 0.5 + l0).backward()
     (q1.sum() * 0.5 + l1).backward()
     assert rel_err(b.grad.cpu().numpy(), a.grad.cpu().numpy()) <= 1e-6
+
+
+def test_reference_checkpoint_file_on_gpu(dev):
+    """The reference-layout checkpoint fixture (written from the reference quantizer) loaded into the GPU
+    module: the eval forward reproduces the outputs the reference produced from that state."""
+    import os
+    from conftest import GOLDEN
+    from vq_vae_amd import EMAVectorQuantizer, checkpoint
+    ck = checkpoint.load_reference_checkpoint(os.path.join(GOLDEN, "g10_checkpoint_light.pt"))
+    g = np.load(os.path.join(GOLDEN, "g10_after_load.npz"))
+    m = EMAVectorQuantizer(ck["num_embeddings"], ck["embedding_dim"], 3.0).to(dev)
+    m.load_state_dict(ck["quantizer_state"], strict=True)
+    m.eval()
+    q, loss, (perp, idx, enc) = m(torch.from_numpy(g["z"]).to(dev))
+    assert np.array_equal(idx.cpu().numpy().reshape(-1), g["indices"].reshape(-1))
+    assert rel_err(q.cpu().numpy(), g["quantized"]) <= 1e-6
+    assert abs(loss.item() - float(g["loss"])) <= 1e-5 * float(g["loss"])
+    assert abs(perp.item() - float(g["perplexity"])) <= 1e-5 * float(g["perplexity"])
+    s = m.get_codebook_stats()
+    got = np.array([s["active_size"], s["utilization"], s["entropy"], s["normalized_entropy"], s["total_usage"]])
+    assert np.allclose(got, g["stats"], rtol=1e-5, atol=0)

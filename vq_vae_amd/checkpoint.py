@@ -61,3 +61,34 @@ def merge_shards(shards: List[Dict[str, torch.Tensor]]) -> Dict[str, torch.Tenso
         else:
             out[k] = shards[0][k].clone()
     return out
+
+
+def load_reference_checkpoint(path: str, map_location="cpu") -> dict:
+    """Read a checkpoint file written by the reference's trainer (full, ``_best`` or ``_best_light``
+    variant, vqvae/vqgan_trainer.py:409-445) with a loader that executes nothing from the file
+    (``torch.load(weights_only=True)``).  Returns the quantizer's six tensors, the (K, D) inferred from
+    them, and the bookkeeping entries the reference stores beside the weights."""
+    ckpt = torch.load(path, map_location=map_location, weights_only=True)
+    if "vqgan_state_dict" not in ckpt:
+        raise KeyError("not a VQGAN trainer checkpoint: no 'vqgan_state_dict'")
+    model_state = ckpt["vqgan_state_dict"]
+    K, D = infer_shape(model_state)
+    cfg = ckpt.get("model_config", {})
+    if cfg and int(cfg.get("vq_num_embed", K)) != K:
+        # the reference refuses such a file too (vqvae/vqgan_trainer.py:484-487)
+        raise ValueError(f"model_config says {cfg['vq_num_embed']} codes, the weights hold {K}")
+    return {"quantizer_state": quantizer_state(model_state), "num_embeddings": K, "embedding_dim": D,
+            "model_state": model_state, "model_config": cfg, "epoch": ckpt.get("epoch", 0),
+            "best_val_loss": ckpt.get("best_val_loss", 0.0), "codebook_stats": ckpt.get("codebook_stats", [])}
+
+
+def light_checkpoint(model_state: Dict[str, torch.Tensor], epoch: int, best_val_loss: float = 0.0,
+                     codebook_stats=None, extra: dict = None) -> dict:
+    """The dict of the reference's light checkpoint variant (vqvae/vqgan_trainer.py:409-423 without
+    the optimizer / scaler entries, :442): ``torch.save`` it and the reference's loaders
+    (vqvae/vqgan_trainer.py:474-526, vqvae/codebook_utilization_check.py:18-53) read it."""
+    out = {"epoch": int(epoch), "vqgan_state_dict": {k: v.detach().cpu() for k, v in model_state.items()},
+           "best_val_loss": float(best_val_loss), "codebook_stats": list(codebook_stats or []),
+           "model_config": model_config(model_state)}
+    out.update(extra or {})
+    return out

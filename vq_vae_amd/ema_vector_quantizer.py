@@ -71,6 +71,44 @@ class LazyOneHot:
     def __repr__(self):
         return f"LazyOneHot(shape={tuple(self.shape)}, device={self.device}, materialized={self._dense is not None})"
 
+    # Python looks operators up on the type, not through __getattr__: each one materialises and delegates.
+    def __len__(self):
+        return self._idx.numel()
+
+    def __getitem__(self, key):
+        if isinstance(key, int) and self._dense is None:
+            # one row costs K floats, not the whole matrix
+            row = torch.zeros(self._K, dtype=torch.float32, device=self._idx.device)
+            row[self._idx[key]] = 1.0
+            return row
+        return self.materialize()[key]
+
+    def __iter__(self):
+        return iter(self.materialize())
+
+    def __bool__(self):
+        return bool(self.materialize())
+
+    def __neg__(self):
+        return -self.materialize()
+
+
+def _delegate(name):
+    def op(self, *args):
+        args = tuple(a.materialize() if isinstance(a, LazyOneHot) else a for a in args)
+        return getattr(self.materialize(), name)(*args)
+    op.__name__ = name
+    return op
+
+
+for _n in ("add", "sub", "mul", "truediv", "floordiv", "mod", "pow", "matmul", "and", "or", "xor"):
+    setattr(LazyOneHot, f"__{_n}__", _delegate(f"__{_n}__"))
+    setattr(LazyOneHot, f"__r{_n}__", _delegate(f"__r{_n}__"))
+for _n in ("eq", "ne", "lt", "le", "gt", "ge", "abs", "invert", "float", "int"):
+    setattr(LazyOneHot, f"__{_n}__", _delegate(f"__{_n}__"))
+LazyOneHot.__hash__ = object.__hash__
+del _n
+
 
 class _QuantizeFn(torch.autograd.Function):
     """forward: the HIP step.  backward: grad_z = grad_q + grad_loss * 2*beta/(N*D) * (z - q),
