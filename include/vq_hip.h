@@ -163,6 +163,21 @@ int vq_code_histogram(const void* idx, int idx_is_64, int64_t M, int K, uint32_t
 int vq_ema_scatter(const float* z, int layout, int64_t N, int D, int64_t HW, const int32_t* idx32, int K,
                    int64_t code_base, int zmax_valid, int32_t* control, float* slabs, int nslab, void* stream);
 
+/*
+ * The same sums for row-major z (layout VQ_LAYOUT_ND, which is also a channels_last tensor's memory)
+ * by counting sort: the rows are ranked by code (per-chunk LDS histograms, a scan, LDS cursors) and
+ * every row is then read whole, once, in code order; lane groups accumulate runs of one code in
+ * registers and add them to the code's accumulator with 64-bit integer atomics (fixed point as
+ * above: the result does not depend on any ordering).  ref: vqvae/ema_vector_quantizer.py:84.
+ * dw gets K*D floats (one slab: pass it on with nslab = 1).  Supported for K <= 16384 and D a
+ * multiple of 4 with D/4 a power of two up to 64 (vq_scatter_sorted_supported); z 16-byte aligned,
+ * work = vq_scatter_sorted_work_bytes(N, K, D) bytes, 256-byte aligned.
+ */
+int vq_scatter_sorted_supported(int K, int D);
+size_t vq_scatter_sorted_work_bytes(int64_t N, int K, int D);
+int vq_ema_scatter_sorted(const float* z, int64_t N, int D, const int32_t* idx32, int K, int64_t code_base,
+                          int zmax_valid, int32_t* control, float* dw, void* work, void* stream);
+
 /* dw[k][c] = sum_s slabs[s][k][c] in slab order (packs the data-parallel all-reduce buffer). */
 int vq_reduce_slabs(const float* slabs, int nslab, int K, int D, float* dw, void* stream);
 

@@ -190,6 +190,47 @@ def test_histogram_and_embed_sums(K, D, shape, dev, ops):
     assert np.array_equal(_bits(ops.reduce_slabs(slabs2).cpu().numpy()), _bits(dw))
 
 
+@pytest.mark.parametrize("K,D,N", [(8192, 256, 40000), (512, 64, 4096), (100, 32, 777), (16384, 16, 5000),
+                                   (64, 4, 3), (700, 128, 70000)])
+def test_sorted_row_major_embed_sums(K, D, N, dev, ops):
+    """Row-major latents: the counting-sort kernels against the oracle, the code-range kernel and
+    themselves (bit-reproducible although the ranking uses atomics); a heavy code, an all-one-code
+    batch, a shard's code_base window and a batch holding NaN / inf."""
+    z = gauss(43, (N, D))
+    rng = np.random.Generator(np.random.PCG64(44))
+    idx = rng.integers(0, K, N, dtype=np.int64)
+    idx[: N // 3] = idx[0]
+    ws = ops.Workspace(dev)
+    zt, it = _t(z, dev), _t(idx.astype(np.int32), dev)
+    dw, nslab = ops.embed_sums(zt, it, K, ws)
+    assert nslab == 1 and dw.shape == (1, K, D)
+    got = dw[0].cpu().numpy().copy()
+    ref = vo.embed_sum(z, idx, K)
+    assert rel_err(got, ref) <= 1e-6
+    assert np.array_equal(got[np.bincount(idx, minlength=K) == 0], np.zeros_like(got[np.bincount(idx, minlength=K) == 0]))
+    again, _ = ops.embed_sums(zt, it, K, ws)
+    assert np.array_equal(_bits(again[0].cpu().numpy()), _bits(got))
+    old, _ = ops.embed_sums(zt, it, K, ops.Workspace(dev), sorted_rows=False)
+    assert rel_err(ops.reduce_slabs(old).cpu().numpy(), got) <= 1e-6
+    # every row on one code
+    one = np.full(N, K - 1, np.int32)
+    dw1, _ = ops.embed_sums(zt, _t(one, dev), K, ws)
+    assert rel_err(dw1[0, K - 1].cpu().numpy(), z.astype(np.float64).sum(0)) <= 1e-6 and float(dw1[0, : K - 1].abs().sum()) == 0
+    # a shard's window of codes: rows outside [code_base, code_base + K_loc) are skipped
+    if K >= 64:
+        lo, K_loc = K // 4, K // 2
+        dws, _ = ops.embed_sums(zt, it, K_loc, ws, code_base=lo)
+        assert rel_err(dws[0].cpu().numpy(), ref[lo: lo + K_loc]) <= 1e-6
+    # NaN / inf in the batch: float accumulation that propagates them like the dense product
+    if N >= 100:
+        zb = z.copy(); zb[5, 1] = np.nan; zb[N - 1, D - 1] = np.inf
+        dwb, _ = ops.embed_sums(_t(zb, dev), it, K, ws)
+        gb = dwb[0].cpu().numpy()
+        assert np.isnan(gb[idx[5], 1]) and np.isinf(gb[idx[N - 1], D - 1])
+        clean = np.ones((K, D), bool); clean[idx[5], 1] = False; clean[idx[N - 1], D - 1] = False
+        assert np.allclose(gb[clean], ref[clean], rtol=0, atol=1e-4 * np.abs(ref).max())
+
+
 def _gpu_state(E, dev):
     K, D = E.shape
     return {"E": _t(E, dev), "ema_w": torch.zeros(K, D, device=dev), "cs": torch.zeros(K, device=dev),

@@ -47,6 +47,10 @@ SIGNATURES = {
     "vq_scatter_slabs_for": (c_int, [c_int64, c_int, c_int, c_int, c_int64]),
     "vq_ema_scatter": (c_int, [c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_int, c_int64, c_int, c_void_p,
                                c_void_p, c_int, c_void_p]),
+    "vq_scatter_sorted_supported": (c_int, [c_int, c_int]),
+    "vq_scatter_sorted_work_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "vq_ema_scatter_sorted": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p,
+                                      c_void_p, c_void_p]),
     "vq_reduce_slabs": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vq_step_scalars": (c_int, [c_void_p, c_int64, c_int64, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p,
                                 c_void_p, c_void_p]),

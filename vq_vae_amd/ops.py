@@ -240,13 +240,21 @@ def histogram(idx: torch.Tensor, K: int, ws: Workspace, out: Optional[torch.Tens
 
 
 def embed_sums(z: torch.Tensor, idx32: torch.Tensor, K: int, ws: Workspace, code_base: int = 0,
-               zmax_valid: bool = False):
+               zmax_valid: bool = False, sorted_rows: bool = True):
     """vq_ema_scatter: returns (slabs [nslab, K, D], nslab).  ``zmax_valid`` says that a search over the
     same ``z`` has just left max|z| in the workspace's control block."""
     lib = _lib.load()
     z = _f32c(z, "latents")
     D = z.shape[1]
     layout, N, HW = _shape_of(z, D)
+    if sorted_rows and (layout == LAYOUT_ND or HW == 1) and z.data_ptr() % 16 == 0 and lib.vq_scatter_sorted_supported(K, D):
+        # row-major latents: counting sort by code, every row read whole once (one slab)
+        dw = ws.get("slabs", K * D * 4, torch.float32)[: K * D].view(1, K, D)
+        work = ws.get("sort_work", lib.vq_scatter_sorted_work_bytes(N, K, D))
+        control = ws.get("control", lib.vq_control_bytes(), torch.int32)
+        check(lib.vq_ema_scatter_sorted(_ptr(z), N, D, _ptr(idx32), K, code_base, 1 if zmax_valid else 0,
+                                        _ptr(control), _ptr(dw), _ptr(work), _stream(z.device)), "vq_ema_scatter_sorted")
+        return dw, 1
     nslab = lib.vq_scatter_slabs_for(N, K, D, layout, HW)
     slabs = ws.get("slabs", nslab * K * D * 4, torch.float32)[: nslab * K * D].view(nslab, K, D)
     control = ws.get("control", lib.vq_control_bytes(), torch.int32)
