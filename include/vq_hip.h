@@ -243,6 +243,21 @@ int vq_backward_gather(const float* grad_q, const float* grad_loss, const float*
                        void* stream);
 
 /*
+ * 1x1 convolution of latent rows on the search's MFMA engine: out[n][o] = sum_c W[o][c] x[n][c] + b[o],
+ * x and out in the same layout (NCHW with C_in / C_out channels, or rows).  ref: the two
+ * nn.Conv2d(.., 1) layers either side of the quantizer, vqvae/custom_vqgan.py:50-51, applied at :68
+ * (quant_conv) and :72 (post_quant_conv); with W transposed it is also their input gradient.
+ * Each output is one fp32 fmaf chain over the input channels in increasing order, started from b[o].
+ * vq_conv1x1_prep lays W ([C_out][C_in] row major, bias may be NULL) out as the `image` the kernel
+ * streams (vq_conv1x1_image_bytes bytes).  C_in in {16, 32, 64, 128, 256}; x, out, W, image 16-byte
+ * aligned.  (NCHW with HW == 1 is the row layout.)
+ */
+size_t vq_conv1x1_image_bytes(int C_out, int C_in);
+int vq_conv1x1_prep(const float* W, const float* bias, int C_out, int C_in, float* image, void* stream);
+int vq_conv1x1(const float* x, int layout, int64_t N, int C_in, int64_t HW, const float* image, int C_out, float* out,
+               void* stream);
+
+/*
  * Re-seed codes in place (maintenance).  ref: the per-code loops of
  * vqvae/ema_vector_quantizer.py:185-196 (reset_dead_codes: noise 0.2, scale 0.1), :262-274
  * (reset_low_usage_codes: noise 0.4, scale 0.2) and the new rows of :131-148 (expand_codebook:

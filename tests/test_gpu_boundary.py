@@ -163,3 +163,61 @@ def test_dict_output_and_state_dict(dev):
         QuantizerBoundary(latent_channels=32, n_embed=K, embed_dim=D)
     with pytest.raises(RuntimeError):
         m(h.cpu())
+
+
+@pytest.mark.parametrize("shape,c_out,bias", [
+    ((3, 256, 32, 32), 256, True),        # the reference's quant_conv at its default width
+    ((2, 64, 5, 7), 100, True),           # HW unaligned, rows % 256 != 0, output channels not a multiple of 64
+    ((1, 16, 1, 1), 8, False),            # a single row, no bias
+    ((700, 128), 96, True),               # rows (what a channels_last tensor is in memory)
+    ((300, 32), 33, False),               # output width not a multiple of 4: scalar stores
+])
+def test_conv1x1_kernel(shape, c_out, bias, dev):
+    """vq_conv1x1 against a float64 evaluation of nn.Conv2d(C, O, 1) (vqvae/custom_vqgan.py:50-51) and
+    against torch's own convolution on the GPU; NaN / inf inputs propagate like a product."""
+    from inputs import gauss
+    from vq_vae_amd import ops
+    c_in = shape[1]
+    x = gauss(1201, shape)
+    W = gauss(1202, (c_out, c_in)) * np.float32(0.3)
+    b = gauss(1203, (c_out,)) if bias else None
+    ws = ops.Workspace(dev)
+    xt, Wt = torch.from_numpy(x).to(dev), torch.from_numpy(W).to(dev)
+    bt = None if b is None else torch.from_numpy(b).to(dev)
+    got = ops.conv1x1(xt, Wt, bt, ws)
+    x4 = x if x.ndim == 4 else x.T[None, :, :, None]            # (N, C) rows as one image of N pixels
+    ref = vo.conv1x1(x4, W[:, :, None, None], b)
+    ref = ref if x.ndim == 4 else ref[0, :, :, 0].T
+    assert got.shape == ref.shape
+    assert rel_err(got.cpu().numpy(), ref) <= 2e-6
+    if x.ndim == 4:
+        tref = torch.nn.functional.conv2d(xt, Wt[:, :, None, None], bt)
+        assert rel_err(got.cpu().numpy(), tref.cpu().numpy()) <= 2e-6
+        cl = ops.conv1x1(xt.contiguous(memory_format=torch.channels_last), Wt, bt, ws)
+        assert cl.is_contiguous(memory_format=torch.channels_last) or cl.shape[2] * cl.shape[3] == 1
+        assert torch.equal(cl.contiguous(), got)                 # same chains: bit-equal across layouts
+    xb = xt.clone().reshape(-1)
+    xb[3] = float("nan"); xb[-1] = float("inf")
+    bad = ops.conv1x1(xb.view(xt.shape), Wt, bt, ws)
+    assert torch.isnan(bad).any() and (torch.isfinite(bad).any() or bad.numel() == c_out)
+
+
+def test_conv1x1_autograd_equals_torch_conv(dev):
+    """The boundary's quant_conv through vq_conv1x1 (forward and input gradient) against nn.Conv2d."""
+    from inputs import gauss
+    from vq_vae_amd.boundary import _Conv1x1Fn
+    from vq_vae_amd import ops
+    C = 64
+    conv = torch.nn.Conv2d(C, C, 1).to(dev)
+    x1 = torch.from_numpy(gauss(1210, (4, C, 9, 9))).to(dev).requires_grad_(True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    w = torch.from_numpy(gauss(1211, (4, C, 9, 9))).to(dev)
+    (conv(x1) * w).sum().backward()
+    gw, gb = conv.weight.grad.clone(), conv.bias.grad.clone()
+    conv.zero_grad()
+    out = _Conv1x1Fn.apply(x2, conv.weight, conv.bias, ops.Workspace(dev))
+    (out * w).sum().backward()
+    assert rel_err(out.detach().cpu().numpy(), conv(x1).detach().cpu().numpy()) <= 2e-6
+    assert rel_err(x2.grad.cpu().numpy(), x1.grad.cpu().numpy()) <= 2e-6
+    assert rel_err(conv.weight.grad.cpu().numpy(), gw.cpu().numpy()) <= 1e-5
+    assert rel_err(conv.bias.grad.cpu().numpy(), gb.cpu().numpy()) <= 1e-5

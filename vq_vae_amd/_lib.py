@@ -63,6 +63,9 @@ SIGNATURES = {
                                   c_void_p, c_void_p, c_void_p]),
     "vq_backward_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_int,
                                    c_void_p, c_float, c_void_p, c_void_p]),
+    "vq_conv1x1_image_bytes": (c_size_t, [c_int, c_int]),
+    "vq_conv1x1_prep": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "vq_conv1x1": (c_int, [c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
     "vq_reseed_stage_bytes": (c_size_t, [c_int, c_int]),
     "vq_reseed_codes": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
                                 c_float, c_float, ctypes.c_uint64, c_void_p, c_void_p]),

@@ -13,9 +13,10 @@ The backward reads the quantized row from a saved copy of the codebook (K x D fl
 N x D), gets the weight gradient from per-code sums of the incoming gradient (the scatter kernel of
 the EMA update) and needs only one N x D x D' product, for the gradient of the latents.
 
-``quant_conv`` stays a stock convolution: its product must exist in memory as the latents ``z`` (the
-search, the EMA scatter and the backward all read it), and the search is specified on the fp32
-values of ``z``, so it cannot be folded into the codebook without changing the distances' bits.
+``quant_conv`` cannot be folded the same way: its product must exist in memory as the latents ``z``
+(the search, the EMA scatter and the backward all read it), and the search is specified on the fp32
+values of ``z``.  It runs as ``vq_conv1x1``, the search kernel's own engine with the convolution's
+weights in the codebook's place (as do the two input-gradient products of the backward).
 """
 from __future__ import annotations
 
@@ -66,7 +67,11 @@ class _QuantizeProjectFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gq = None
             if grad_out is not None:
-                gq = F.conv2d(grad_out.float(), W.t().reshape(D, DP, 1, 1))   # W^T grad_out, per latent
+                go = grad_out.float()
+                if ops.conv1x1_supported(go, D, DP):
+                    gq = ops.conv1x1(go, W.t().contiguous(), None, ctx.ws, "post_conv_t_image")
+                else:
+                    gq = F.conv2d(go, W.t().reshape(D, DP, 1, 1))   # W^T grad_out, per latent
             grad_z = ops.backward_gather(gq, grad_loss, z, E_pre, idx, ctx.coef)
         if grad_out is not None and (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])):
             G = ops.code_sums(grad_out, idx.to(torch.int32), K, ctx.ws)          # (K, D')
@@ -75,6 +80,38 @@ class _QuantizeProjectFn(torch.autograd.Function):
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 grad_b = G.sum(0)
         return grad_z, grad_w, grad_b, None, None
+
+
+class _Conv1x1Fn(torch.autograd.Function):
+    """A 1x1 convolution (vqvae/custom_vqgan.py:50, applied at :68) whose forward and input gradient
+    run on the search's MFMA engine (``vq_conv1x1``: the weights stream through LDS like a 256-row
+    codebook); the weight gradient, a reduction over all N rows, stays with torch's convolution
+    backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, ws):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        ctx.ws = ws
+        return ops.conv1x1(x, weight, bias, ws, "quant_conv_image")
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, weight = ctx.saved_tensors
+        O, C = weight.shape[0], weight.shape[1]
+        grad_x = grad_w = grad_b = None
+        go = grad_out.float()
+        if ctx.needs_input_grad[0]:
+            Wt = weight.detach().reshape(O, C).t().contiguous()
+            if ops.conv1x1_supported(go, C, O):
+                grad_x = ops.conv1x1(go, Wt, None, ctx.ws, "quant_conv_t_image")
+            else:
+                grad_x = F.conv2d(go, Wt.reshape(C, O, 1, 1))
+        if ctx.needs_input_grad[1]:
+            grad_w = torch.nn.grad.conv2d_weight(x.float(), weight.shape, go).to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            grad_b = go.sum((0, 2, 3))
+        return grad_x, grad_w, grad_b, None
 
 
 class QuantizerBoundary(nn.Module):
@@ -103,7 +140,12 @@ class QuantizerBoundary(nn.Module):
         produced one, then ``quant_conv``."""
         if h.shape[1] == 2 * self.quant_conv.in_channels:
             h, _ = torch.chunk(h, 2, dim=1)
-        return self.quant_conv(h)
+        qc = self.quant_conv
+        if h.is_cuda and h.dim() == 4 and ops.conv1x1_supported(h, qc.out_channels, qc.in_channels):
+            if not h.is_contiguous() and not h.is_contiguous(memory_format=torch.channels_last):
+                h = h.contiguous()
+            return _Conv1x1Fn.apply(h, qc.weight, qc.bias, self.quantize._workspace(h.device))
+        return qc(h)       # channel counts outside the kernel's set (and the host-side shape checks on CPU)
 
     def forward(self, h: torch.Tensor, temperature: float = 1.0):
         """h: encoder output (B, C, H, W).  Returns ``(decoder_input, commitment_loss,

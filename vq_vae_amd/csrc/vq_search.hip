@@ -450,6 +450,162 @@ __global__ __launch_bounds__(512 / CT, 2 / CT) void vq_search_mfma_kernel(Search
 }
 
 // ---------------------------------------------------------------------------------------
+// 1x1 convolution of the latents' rows on the same engine: out[n][o] = sum_c W[o][c] x[n][c] + b[o]
+// (vqvae/custom_vqgan.py:50-51, applied at :68 and :72).  The weights take the codebook's place --
+// their image streams through LDS, the slot of a stage's norms carries the bias -- the 32-row tile
+// of x stays in registers, and where the search scans a finished accumulator tile this kernel
+// stores it in x's layout.  An output is one fmaf chain over the input channels in increasing
+// order, started from the bias.
+// ---------------------------------------------------------------------------------------
+struct ConvArgs {
+  const float* x;
+  const float* image;   // weights in image order, bias in the norms slot
+  float* out;
+  int64_t N;
+  int64_t HW;
+  int Cout;
+  int nstages;
+};
+
+template <bool NCHW>
+__device__ __forceinline__ void conv_store_tile(const f32x16& c, int code0, int h, int Cout, bool valid, float* obase,
+                                                int64_t cstride) {
+  if (!valid) return;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int d0 = code0 + 8 * q + 4 * h;
+    if (!NCHW && d0 + 3 < Cout && (Cout & 3) == 0) {
+      f32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = c[4 * q + r];
+      *reinterpret_cast<f32x4*>(obase + d0) = o;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (d0 + r < Cout) obase[(int64_t)(d0 + r) * cstride] = c[4 * q + r];
+    }
+  }
+}
+
+template <int D, bool NCHW>
+__global__ __launch_bounds__(512, 2) void vq_conv1x1_kernel(ConvArgs a) {
+  constexpr int NW = 8;
+  constexpr int S = D / 2;
+  constexpr int G = D / 8;
+  constexpr int STAGE_F = VQ_STAGE_CODES * D + 256;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int64_t row0 = (int64_t)blockIdx.x * VQ_WG_ROWS + wave * 32;
+
+  stage_copy<D, NW>(a.image, 0, lds, wave, lane);
+
+  // x tile into registers in B-operand order: xr[s] = x[row][2s + h]
+  float xr[S];
+  int64_t n = row0 + j;
+  const bool valid = n < a.N;
+  if (!valid) n = a.N - 1;
+  float* obase;
+  int64_t cstride;
+  if (NCHW) {
+    const int64_t b = n / a.HW, hw = n - b * a.HW;
+    const float* src = a.x + (b * D + h) * a.HW + hw;
+    const int64_t xstride = 2 * a.HW;
+#pragma unroll
+    for (int s = 0; s < S; ++s) xr[s] = src[(int64_t)s * xstride];
+    obase = a.out + b * a.Cout * a.HW + hw;
+    cstride = a.HW;
+  } else {
+    // (dword loads: a 16-byte load would hold four registers to leave two, and the tile fills the file)
+    const float* src = a.x + n * D + h;
+#pragma unroll
+    for (int m = 0; m < D / 4; ++m) {
+      xr[2 * m] = src[4 * m];
+      xr[2 * m + 1] = src[4 * m + 2];
+    }
+    obase = a.out + n * a.Cout;
+    cstride = 1;
+  }
+
+  f32x16 cA, cB;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) cB[i] = 0.0f;
+
+  __syncthreads();
+
+  int cur = 0;
+  for (int st = 0; st < a.nstages; ++st) {
+    float* buf = lds + cur * STAGE_F;
+    if (st + 1 < a.nstages) stage_copy<D, NW>(a.image, st + 1, lds + (cur ^ 1) * STAGE_F, wave, lane);
+    const f32x4* A = reinterpret_cast<const f32x4*>(buf) + lane;
+    const f32x4* bs = reinterpret_cast<const f32x4*>(buf + VQ_STAGE_CODES * D) + h;
+
+    // first half: output channels [64 st, 64 st + 32) into set A, starting from their bias;
+    // store set B of stage st-1
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 b4 = bs[2 * q];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cA[4 * q + r] = b4[r];
+    }
+    {
+      f32x4 af = A[0];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const f32x4 an = A[(g + 1 < G ? g + 1 : g) * 64];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cA = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], xr[4 * g + q], cA, 0, 0, 0);
+        af = an;
+      }
+    }
+    if (st > 0) conv_store_tile<NCHW>(cB, (st - 1) * VQ_STAGE_CODES + 32, h, a.Cout, valid, obase, cstride);
+
+    // second half: output channels [64 st + 32, 64 st + 64) into set B; store set A
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 b4 = bs[8 + 2 * q];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cB[4 * q + r] = b4[r];
+    }
+    {
+      f32x4 af = A[G * 64];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const f32x4 an = A[(G + (g + 1 < G ? g + 1 : g)) * 64];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cB = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], xr[4 * g + q], cB, 0, 0, 0);
+        af = an;
+      }
+    }
+    conv_store_tile<NCHW>(cA, st * VQ_STAGE_CODES, h, a.Cout, valid, obase, cstride);
+
+    __syncthreads();
+    cur ^= 1;
+  }
+  conv_store_tile<NCHW>(cB, (a.nstages - 1) * VQ_STAGE_CODES + 32, h, a.Cout, valid, obase, cstride);
+}
+
+template <int D>
+int launch_conv(const ConvArgs& a, bool nchw, hipStream_t s) {
+  const size_t lds_bytes = 2 * vq_stage_floats(D) * 4 + 256;
+  static bool attr_done[2][64] = {};
+  int dev = 0;
+  VQ_CHECK_HIP(hipGetDevice(&dev));
+  const void* kern = nchw ? reinterpret_cast<const void*>(vq_conv1x1_kernel<D, true>)
+                          : reinterpret_cast<const void*>(vq_conv1x1_kernel<D, false>);
+  if (!attr_done[nchw][dev & 63]) {
+    VQ_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    attr_done[nchw][dev & 63] = true;
+  }
+  const int64_t blocks = (a.N + VQ_WG_ROWS - 1) / VQ_WG_ROWS;
+  if (nchw) hipLaunchKernelGGL((vq_conv1x1_kernel<D, true>), dim3((unsigned)blocks), dim3(512), lds_bytes, s, a);
+  else hipLaunchKernelGGL((vq_conv1x1_kernel<D, false>), dim3((unsigned)blocks), dim3(512), lds_bytes, s, a);
+  return vq_hip_status(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------
 // Exact scalar search: any D, torch.argmin's NaN rule, literal temperature division.
 // One workgroup handles 8 rows at a time; thread t scans codes t, t+256, ...; the dot
 // product is the same fmaf chain the MFMA computes, so both kernels agree bit for bit on
@@ -682,7 +838,9 @@ __global__ __launch_bounds__(256) void vq_search_rows_kernel(SearchArgs a, int D
 // ---------------------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(64) void vq_prep_image_kernel(const float* __restrict__ E, int K, float* __restrict__ image,
-                                                           float* __restrict__ e2, int32_t* control) {
+                                                           float* __restrict__ e2, int32_t* control,
+                                                           const float* __restrict__ bias = nullptr,
+                                                           int conv_image = 0) {
   constexpr int G = D / 8;
   const int lane = threadIdx.x;
   const int i = lane & 31, h = lane >> 5;
@@ -708,7 +866,10 @@ __global__ __launch_bounds__(64) void vq_prep_image_kernel(const float* __restri
     for (int q = 0; q < 4; ++q) p = __builtin_fmaf(o[q], o[q], p);
   }
   const float n2 = p + __shfl_xor(p, 32);
-  if (h == 0) {
+  if (h == 0 && conv_image) {
+    // image of a 1x1 convolution's weights: the slot of the norms carries the bias
+    st_base[VQ_STAGE_CODES * D + rt * 32 + i] = (real && bias) ? bias[code] : 0.0f;
+  } else if (h == 0) {
     const float v = real ? n2 : __builtin_inff();
     e2[code] = v;
     st_base[VQ_STAGE_CODES * D + rt * 32 + i] = v;
@@ -1097,6 +1258,47 @@ int vq_gather_st(const float* z, int layout, int64_t N, int D, int64_t HW, const
                      layout == VQ_LAYOUT_NCHW ? 1 : 0, N, D, layout == VQ_LAYOUT_NCHW ? HW : 1, E, K, idx64, q_out,
                      loss_partial, (const int32_t*)nullptr);
   return vq_hip_status(hipGetLastError());
+}
+
+size_t vq_conv1x1_image_bytes(int C_out, int C_in) { return vq_image_bytes(C_out, C_in); }
+
+int vq_conv1x1_prep(const float* W, const float* bias, int C_out, int C_in, float* image, void* stream) {
+  if (!W || !image || C_out <= 0 || C_in <= 0) return VQ_ERR_INVALID_ARG;
+  if (!vq_fast_dim(C_in)) return VQ_ERR_UNSUPPORTED;
+  if (!aligned16(W) || !aligned16(image)) return VQ_ERR_INVALID_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int tiles = vq_kpad(C_out) / 32;
+  float* none = nullptr;
+  int32_t* nocontrol = nullptr;
+  switch (C_in) {
+    case 16: hipLaunchKernelGGL(vq_prep_image_kernel<16>, dim3(tiles), dim3(64), 0, s, W, C_out, image, none, nocontrol, bias, 1); break;
+    case 32: hipLaunchKernelGGL(vq_prep_image_kernel<32>, dim3(tiles), dim3(64), 0, s, W, C_out, image, none, nocontrol, bias, 1); break;
+    case 64: hipLaunchKernelGGL(vq_prep_image_kernel<64>, dim3(tiles), dim3(64), 0, s, W, C_out, image, none, nocontrol, bias, 1); break;
+    case 128: hipLaunchKernelGGL(vq_prep_image_kernel<128>, dim3(tiles), dim3(64), 0, s, W, C_out, image, none, nocontrol, bias, 1); break;
+    default: hipLaunchKernelGGL(vq_prep_image_kernel<256>, dim3(tiles), dim3(64), 0, s, W, C_out, image, none, nocontrol, bias, 1); break;
+  }
+  return vq_hip_status(hipGetLastError());
+}
+
+int vq_conv1x1(const float* x, int layout, int64_t N, int C_in, int64_t HW, const float* image, int C_out, float* out,
+               void* stream) {
+  if (!x || !image || !out || N <= 0 || C_in <= 0 || C_out <= 0) return VQ_ERR_INVALID_ARG;
+  if (layout != VQ_LAYOUT_ND && layout != VQ_LAYOUT_NCHW) return VQ_ERR_INVALID_ARG;
+  if (layout == VQ_LAYOUT_NCHW && (HW <= 0 || N % HW != 0)) return VQ_ERR_INVALID_ARG;
+  if (!vq_fast_dim(C_in) || N >= (int64_t)1 << 31) return VQ_ERR_UNSUPPORTED;
+  if (!aligned16(x) || !aligned16(image) || !aligned16(out)) return VQ_ERR_INVALID_ARG;
+  const bool nchw = layout == VQ_LAYOUT_NCHW && HW > 1;
+  ConvArgs a{};
+  a.x = x; a.image = image; a.out = out; a.N = N; a.HW = nchw ? HW : 1; a.Cout = C_out;
+  a.nstages = vq_kpad(C_out) / VQ_STAGE_CODES;
+  hipStream_t s = (hipStream_t)stream;
+  switch (C_in) {
+    case 16: return launch_conv<16>(a, nchw, s);
+    case 32: return launch_conv<32>(a, nchw, s);
+    case 64: return launch_conv<64>(a, nchw, s);
+    case 128: return launch_conv<128>(a, nchw, s);
+    default: return launch_conv<256>(a, nchw, s);
+  }
 }
 
 int vq_pairwise_search_launch(const float* E, const float* image, const float* e2, int K, int D, int64_t row_base,

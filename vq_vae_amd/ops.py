@@ -434,6 +434,40 @@ def backward_gather(grad_q, grad_loss, z: torch.Tensor, E: torch.Tensor, idx64: 
     return grad_z
 
 
+def conv1x1_supported(x: torch.Tensor, c_out: int, c_in: int) -> bool:
+    """Shapes vq_conv1x1 covers: fp32 GPU rows with 16 / 32 / 64 / 128 / 256 input channels."""
+    return x.is_cuda and c_in in (16, 32, 64, 128, 256) and x.dim() in (2, 4) and x.shape[1] == c_in and c_out > 0
+
+
+def conv1x1(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], ws: Workspace,
+            image_name: str = "conv_image") -> torch.Tensor:
+    """out[n, o] = sum_c W[o, c] x[n, c] + b[o] on the search's MFMA engine (the 1x1 convolutions of
+    vqvae/custom_vqgan.py:50-51).  x: (B, C, H, W) in either memory format, or (N, C) rows; the
+    result has x's layout.  weight: (O, C) or (O, C, 1, 1)."""
+    lib = _lib.load()
+    _require_cuda(x, "input")
+    if x.dtype != torch.float32:
+        x = x.float()
+    W = _f32c(weight.detach().reshape(weight.shape[0], -1), "weight")
+    c_out, c_in = W.shape
+    rows, back = _rows_view(x)
+    if rows is not None:
+        return back(conv1x1(rows, W, bias, ws, image_name))
+    x = _f32c(x, "input")
+    if not conv1x1_supported(x, c_out, c_in):
+        raise RuntimeError(f"vq_conv1x1 needs 16/32/64/128/256 input channels, got input {tuple(x.shape)} for a "
+                           f"({c_out}, {c_in}) weight")
+    layout, N, HW = _shape_of(x, c_in)
+    b = None if bias is None else _f32c(bias.detach(), "bias")
+    image = ws.get(image_name, lib.vq_conv1x1_image_bytes(c_out, c_in), torch.float32)
+    s = _stream(x.device)
+    check(lib.vq_conv1x1_prep(_ptr(W), _ptr(b), c_out, c_in, _ptr(image), s), "vq_conv1x1_prep")
+    shape = (x.shape[0], c_out, x.shape[2], x.shape[3]) if x.dim() == 4 else (N, c_out)
+    out = torch.empty(shape, dtype=torch.float32, device=x.device)
+    check(lib.vq_conv1x1(_ptr(x), layout, N, c_in, HW, _ptr(image), c_out, _ptr(out), s), "vq_conv1x1")
+    return out
+
+
 def quantize_step(z: torch.Tensor, E: torch.Tensor, ema_w, cluster_size, usage, *, beta: float, decay: float,
                   epsilon: float, temperature: float, training: bool, ws: Workspace, want_dmin: bool = False,
                   stats_reduce=None, search_events=None, filtered: bool = False,
