@@ -8,6 +8,7 @@ import torch
 
 from conftest import GOLDEN, rel_err
 from inputs import gauss
+from oracle import vq_oracle as vo
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -290,3 +291,40 @@ def test_reference_checkpoint_file_on_gpu(dev):
     s = m.get_codebook_stats()
     got = np.array([s["active_size"], s["utilization"], s["entropy"], s["normalized_entropy"], s["total_usage"]])
     assert np.allclose(got, g["stats"], rtol=1e-5, atol=0)
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_empty_batch_behaves_like_the_reference(training, dev):
+    """A batch without rows (B = 0).  The reference's forward (run on CPU for this test's expectations)
+    returns an empty quantized tensor and index list, NaN loss and perplexity, and in training mode
+    applies the EMA update with all-zero statistics: cluster sizes and sums decay, usage is unchanged,
+    and a fresh codebook (all cluster sizes 0) turns into 0/0."""
+    K, D = 64, 16
+    E = gauss(1301, (K, D)) * np.float32(0.5)
+    m = make(K, D, 3.0, 0.95, E, dev)
+    m.train()
+    m(torch.from_numpy(gauss(1302, (2, D, 4, 4))).to(dev))          # one real step: a non-trivial state
+    st = vo.OracleState(embedding=m.embedding.weight.detach().cpu().numpy().copy(), ema_w=m.ema_w.cpu().numpy().copy(),
+                        ema_cluster_size=m.ema_cluster_size.cpu().numpy().copy(),
+                        usage_count=m.usage_count.cpu().numpy().copy())
+    m.train(training)
+    z = torch.zeros(0, D, 4, 4, device=dev, requires_grad=True)
+    q, loss, (perp, idx, enc) = m(z)
+    assert q.shape == (0, D, 4, 4) and idx.shape == (0, 1) and enc.shape == (0, K)
+    assert torch.isnan(loss) and torch.isnan(perp)
+    (q.sum() + loss).backward()
+    assert z.grad.shape == z.shape
+    before = (st.embedding.copy(), st.ema_w.copy(), st.ema_cluster_size.copy(), st.usage_count.copy())
+    if training:
+        vo.ema_update(np.zeros(K, np.int64), np.zeros((K, D), np.float32), st.usage_count, st.ema_cluster_size, st.ema_w,
+                      st.embedding, 0.95, 1e-5)
+        assert not np.array_equal(st.ema_cluster_size, before[2])
+    assert rel_err(m.ema_cluster_size.cpu().numpy(), st.ema_cluster_size) <= 1e-6
+    assert rel_err(m.ema_w.cpu().numpy(), st.ema_w) <= 1e-6
+    assert np.allclose(m.embedding.weight.detach().cpu().numpy(), st.embedding, rtol=1e-5, atol=1e-7, equal_nan=True)
+    assert np.array_equal(m.usage_count.cpu().numpy(), before[3])
+    if training:
+        fresh = make(K, D, 3.0, 0.95, E, dev)
+        fresh.train()
+        fresh(torch.zeros(0, D, 2, 2, device=dev))
+        assert torch.isnan(fresh.embedding.weight).all() and float(fresh.ema_cluster_size.abs().sum()) == 0

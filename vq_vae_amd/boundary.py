@@ -53,7 +53,7 @@ class _QuantizeProjectFn(torch.autograd.Function):
         ctx.save_for_backward(z, res.indices, E_pre, weight)
         ctx.has_bias = bias is not None
         ctx.ws = module._workspace(z.device)
-        ctx.coef = 2.0 * float(module.commitment_cost) / float(z.numel())
+        ctx.coef = 2.0 * float(module.commitment_cost) / float(max(z.numel(), 1))
         ctx.mark_non_differentiable(res.perplexity, res.indices)
         return res.quantized, res.loss, res.perplexity, res.indices
 

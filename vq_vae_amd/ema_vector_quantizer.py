@@ -119,7 +119,7 @@ class _QuantizeFn(torch.autograd.Function):
     def forward(ctx, z: torch.Tensor, module: "EMAVectorQuantizer", temperature: float):
         res = module._run_step(z, temperature)
         ctx.save_for_backward(z, res.quantized)
-        ctx.coef = 2.0 * float(module.commitment_cost) / float(z.numel())
+        ctx.coef = 2.0 * float(module.commitment_cost) / float(max(z.numel(), 1))
         ctx.mark_non_differentiable(res.perplexity, res.indices)
         return res.quantized, res.loss, res.perplexity, res.indices
 

@@ -325,6 +325,8 @@ def backward(grad_q, grad_loss, z, q_st, coef: float) -> torch.Tensor:
     z = same(z, "latents")
     q_st = same(q_st, "quantized")
     grad_z = torch.empty_like(z)
+    if z.numel() == 0:
+        return grad_z
     gq = None if grad_q is None else same(grad_q, "grad_quantized")
     gl = None if grad_loss is None else _f32c(grad_loss, "grad_loss")
     check(lib.vq_backward(_ptr(gq), _ptr(gl), _ptr(z), _ptr(q_st), z.numel(), float(coef), _ptr(grad_z),
@@ -357,6 +359,8 @@ def onehot(idx64: torch.Tensor, K: int) -> torch.Tensor:
     idx64 = idx64.contiguous().view(-1)
     N = idx64.numel()
     enc = torch.empty(N, K, dtype=torch.float32, device=idx64.device)
+    if N == 0:
+        return enc
     check(lib.vq_onehot(_ptr(idx64), N, K, _ptr(enc), _stream(idx64.device)), "vq_onehot")
     return enc
 
@@ -429,6 +433,8 @@ def backward_gather(grad_q, grad_loss, z: torch.Tensor, E: torch.Tensor, idx64: 
         raise RuntimeError(f"grad_quantized has shape {tuple(gq.shape)}, latents {tuple(z.shape)}")
     gl = None if grad_loss is None else _f32c(grad_loss, "grad_loss")
     grad_z = torch.empty_like(z)
+    if z.numel() == 0:
+        return grad_z
     check(lib.vq_backward_gather(_ptr(gq), _ptr(gl), _ptr(z), layout, N, D, HW, _ptr(E), K, _ptr(idx64), float(coef),
                                  _ptr(grad_z), _stream(z.device)), "vq_backward_gather")
     return grad_z
@@ -496,6 +502,8 @@ def quantize_step(z: torch.Tensor, E: torch.Tensor, ema_w, cluster_size, usage, 
                             project=project)
         out.quantized = back(out.quantized)
         return out
+    if z.numel() == 0:
+        return _empty_step(z, E, ema_w, cluster_size, usage, decay, epsilon, training, ws, stats_reduce, project)
     r = search(z, E, ws, temperature=temperature, want_quantized=project is None, want_dmin=want_dmin,
                events=search_events, filtered=filtered)
     if project is not None:
@@ -522,6 +530,33 @@ def quantize_step(z: torch.Tensor, E: torch.Tensor, ema_w, cluster_size, usage, 
         if training:
             ema_update(None, dw, usage, cluster_size, ema_w, E, decay, epsilon, counts64=counts64)
     return StepResult(r["quantized"], loss, perp, r["indices"], counts, r["dmin"])
+
+
+def _empty_step(z, E, ema_w, cluster_size, usage, decay, epsilon, training, ws, stats_reduce, project) -> StepResult:
+    """A batch without rows, as the reference's forward treats it: empty outputs, loss and perplexity
+    NaN (means over nothing, vqvae/ema_vector_quantizer.py:92, :105), and in training mode the EMA
+    update with all-zero statistics (:67-89: the cluster sizes and sums decay, a fresh codebook
+    becomes 0/0)."""
+    K, D = E.shape
+    dev = z.device
+    shape = list(z.shape)
+    if project is not None:
+        shape[1] = project.shape[1]
+    q = torch.empty(shape, dtype=torch.float32, device=dev)
+    nan = torch.full((), float("nan"), dtype=torch.float32, device=dev)
+    counts = ws.get("counts", K * 4, torch.int32)
+    counts.zero_()
+    if training:
+        dw = ws.get("dw", K * D * 4, torch.float32)[: K * D].view(K, D)
+        dw.zero_()
+        if stats_reduce is None:
+            ema_update(counts, dw, usage, cluster_size, ema_w, E, decay, epsilon)
+        else:
+            counts64, dw, _ = stats_reduce(counts, dw, 0)
+            ema_update(None, dw, usage, cluster_size, ema_w, E, decay, epsilon, counts64=counts64)
+    elif stats_reduce is not None:
+        stats_reduce(counts, None, 0)       # keep the collective sequence of the other ranks
+    return StepResult(q, nan, nan.clone(), torch.empty(0, dtype=torch.int64, device=dev), counts, None)
 
 
 def pack_dist_index(dmin: torch.Tensor, idx64: torch.Tensor) -> torch.Tensor:
