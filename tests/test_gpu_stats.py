@@ -235,3 +235,36 @@ def test_analyzer_front_end(dev, tmp_path):
     stats.save_codebook_stats(res, str(path))
     saved = json.loads(path.read_text())
     assert saved["n_embed"] == K and len(saved["index_counts"]) == K and len(saved["probs"]) == K
+
+
+def test_interpolation_smoothness(dev):
+    """Quantized interpolation paths: indices equal the oracle's on every interpolated point, the
+    path metrics equal a NumPy float64 evaluation of their definitions."""
+    from vq_vae_amd import latent_stats
+    K, D, P, steps = 512, 64, 40, 12
+    E = gauss(1401, (K, D)) * np.float32(0.5)
+    a, b = gauss(1402, (P, D)), gauss(1403, (P, D))
+    b[3] = a[3]                                                   # a pair with identical ends
+    r = latent_stats.interpolation_smoothness(torch.from_numpy(E).to(dev), torch.from_numpy(a).to(dev),
+                                              torch.from_numpy(b).to(dev), steps=steps)
+    t = torch.linspace(0.0, 1.0, steps + 1, dtype=torch.float32).view(1, steps + 1, 1)
+    z = (torch.from_numpy(a).unsqueeze(1) * (1.0 - t) + torch.from_numpy(b).unsqueeze(1) * t).reshape(-1, D).numpy()
+    idx, _ = vo.search(z, E)
+    idx = idx.reshape(P, steps + 1)
+    got = r["indices"].cpu().numpy()
+    # the interpolated points are computed on the GPU in fp32: equal up to fp32 rounding of the lerp,
+    # which can flip an index only at an exact tie -- none in this data
+    assert np.array_equal(got, idx)
+    q = E[idx].astype(np.float64)
+    step_len = np.linalg.norm(q[:, 1:] - q[:, :-1], axis=2)
+    direct = np.linalg.norm(q[:, -1] - q[:, 0], axis=1)
+    switches = (idx[:, 1:] != idx[:, :-1]).sum(1)
+    assert np.array_equal(r["per_pair"]["code_switches"].cpu().numpy(), switches)
+    assert np.array_equal(r["per_pair"]["distinct_codes"].cpu().numpy(), np.array([len(set(row)) for row in idx]))
+    ok = direct > 0
+    assert abs(r["path_length_ratio"] - (step_len.sum(1)[ok] / direct[ok]).mean()) <= 1e-9
+    assert np.isnan(r["per_pair"]["path_length_ratio"].cpu().numpy()[~ok]).all()
+    assert switches[3] == 0 and np.isnan(r["per_pair"]["max_jump_ratio"].cpu().numpy()[3])
+    assert abs(r["code_switches"] - switches.mean()) <= 1e-12
+    qerr = ((z.reshape(P, steps + 1, D).astype(np.float64) - q) ** 2).sum(2).mean(1)
+    assert abs(r["quantization_error"] - qerr.mean()) <= 1e-6 * qerr.mean()

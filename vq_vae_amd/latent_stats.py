@@ -122,3 +122,60 @@ def quantization_consistency(latents: torch.Tensor, quantized: torch.Tensor) -> 
         "mean_cosine_similarity": float(cos.mean()),
         "sqnr_db": float(-10.0 * math.log10(max(rel_total, 1e-300))),
     }
+
+
+@torch.no_grad()
+def interpolation_smoothness(codebook: torch.Tensor, start: torch.Tensor, end: torch.Tensor, steps: int = 16,
+                             ws=None) -> dict:
+    """Smoothness of quantized interpolation paths (the reference's README.md:31-32 lists
+    "interpolation smoothness" among its latent-space continuity analyses; it holds no code for it,
+    so the definition is this package's own).
+
+    For P pairs of latent vectors ``start[p]``, ``end[p]`` ((P, D) tensors on the GPU) the points
+    z_t = (1 - t) start + t end, t = 0, 1/steps, ..., 1, are quantized with the HIP search
+    (nearest code, lowest index on ties, as vqvae/ema_vector_quantizer.py:42-53).  Reported, each as
+    the mean over the pairs plus the per-pair tensors:
+
+    * ``code_switches``      how often the code changes along a path (0 .. steps)
+    * ``distinct_codes``     how many different codes a path visits
+    * ``path_length_ratio``  sum of ||q_{t+1} - q_t|| over ||q_last - q_first|| (1 = the quantized path is
+                             as direct as its end points allow; NaN where both ends share a code)
+    * ``max_jump_ratio``     largest single step ||q_{t+1} - q_t|| over ||end - start|| / steps, the
+                             length of one interpolation step before quantization
+    * ``quantization_error`` mean ||z_t - q_t||^2 along the path
+    """
+    from . import ops
+    if start.shape != end.shape or start.dim() != 2:
+        raise RuntimeError(f"start and end must both be (P, D), got {tuple(start.shape)} and {tuple(end.shape)}")
+    if steps < 1:
+        raise ValueError("steps must be at least 1")
+    E = ops._f32c(codebook, "codebook")
+    a = ops._f32c(start, "start")
+    b = ops._f32c(end, "end")
+    P, D = a.shape
+    t = torch.linspace(0.0, 1.0, steps + 1, device=a.device, dtype=torch.float32).view(1, steps + 1, 1)
+    z = (a.unsqueeze(1) * (1.0 - t) + b.unsqueeze(1) * t).reshape(P * (steps + 1), D).contiguous()
+    ws = ws or ops.Workspace(a.device)
+    idx = ops.search(z, E, ws, want_quantized=False)["indices"].view(P, steps + 1)
+    q = E[idx]                                                   # (P, steps + 1, D)
+    step_len = (q[:, 1:] - q[:, :-1]).double().norm(dim=2)        # (P, steps)
+    direct = (q[:, -1] - q[:, 0]).double().norm(dim=1)
+    switches = (idx[:, 1:] != idx[:, :-1]).sum(1)
+    srt = idx.sort(dim=1).values
+    distinct = 1 + (srt[:, 1:] != srt[:, :-1]).sum(1)
+    nan = torch.full_like(direct, float("nan"))
+    ratio = torch.where(direct > 0, step_len.sum(1) / direct.clamp_min(1e-300), nan)
+    unit = (b - a).double().norm(dim=1) / steps
+    jump = torch.where(unit > 0, step_len.max(1).values / unit.clamp_min(1e-300), torch.full_like(unit, float("nan")))
+    qerr = (z.view(P, steps + 1, D) - q).double().pow(2).sum(2).mean(1)
+
+    def mean(x):
+        x = x.double()
+        ok = ~torch.isnan(x)
+        return float(x[ok].mean()) if bool(ok.any()) else float("nan")
+
+    return {"steps": steps, "pairs": P, "indices": idx,
+            "code_switches": mean(switches), "distinct_codes": mean(distinct),
+            "path_length_ratio": mean(ratio), "max_jump_ratio": mean(jump), "quantization_error": mean(qerr),
+            "per_pair": {"code_switches": switches, "distinct_codes": distinct, "path_length_ratio": ratio,
+                         "max_jump_ratio": jump, "quantization_error": qerr}}
