@@ -275,6 +275,38 @@ def test_training_trajectory(K, D, shape, decay, beta, T, dev, ops):
     assert rel_err(g["cs"].cpu().numpy(), free.ema_cluster_size) <= 1e-4
 
 
+@pytest.mark.parametrize("K,D,shape", [
+    (1, 16, (1, 16, 2, 3)),          # a single code: every row picks it
+    (2, 8, (3, 8, 1, 5)),            # D = 8: exact kernel
+    (3, 1, (2, 1, 4, 4)),            # one channel
+    (65, 16, (1, 16, 1, 1)),         # one row, one code beyond a stage
+    (33, 32, (700, 32)),             # row-major, ragged everything
+    (7, 100, (2, 100, 3, 3)),        # channel count outside the matrix-core set
+    (4096, 128, (1, 128, 16, 17)),   # HW = 272 (not a multiple of 32), codebook split of a small batch
+])
+def test_edge_shapes_two_training_steps(K, D, shape, dev, ops):
+    """Degenerate and ragged shapes through the whole training step, two steps from a fresh state (the
+    second one starts from a codebook whose unused rows are zero vectors, ties at distance ||z||^2)."""
+    E0 = gauss(1501, (K, D)) * np.float32(0.7)
+    ws = ops.Workspace(dev)
+    g = _gpu_state(E0, dev)
+    for step in range(2):
+        z = gauss(1510 + step, shape)
+        synced = vo.OracleState(g["E"].cpu().numpy().copy(), g["cs"].cpu().numpy().copy(),
+                                g["ema_w"].cpu().numpy().copy(), g["usage"].cpu().numpy().copy())
+        if z.ndim == 2:      # rows for the GPU; the oracle's forward takes them as one image of N pixels
+            o_ref = vo.forward(np.ascontiguousarray(z.T)[None, :, :, None], synced, 3.0, 0.95, 1e-5, 1.0, True)
+            o_ref["quantized"] = np.ascontiguousarray(o_ref["quantized"][0, :, :, 0].T)
+        else:
+            o_ref = vo.forward(z, synced, 3.0, 0.95, 1e-5, 1.0, True)
+        out = ops.quantize_step(_t(z, dev), g["E"], g["ema_w"], g["cs"], g["usage"], beta=3.0, decay=0.95,
+                                epsilon=1e-5, temperature=1.0, training=True, ws=ws)
+        torch.cuda.synchronize()
+        _check_step(out, o_ref, g, synced)
+        counts = out.counts.cpu().numpy().view(np.uint32).astype(np.int64)
+        assert np.array_equal(counts, np.asarray(o_ref["counts"]).astype(np.int64))
+
+
 def test_eval_step_leaves_state_alone(dev, ops):
     K, D = 512, 64
     E0 = gauss(72, (K, D)) * np.float32(0.5)

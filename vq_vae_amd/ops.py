@@ -510,7 +510,7 @@ def quantize_step(z: torch.Tensor, E: torch.Tensor, ema_w, cluster_size, usage, 
         # the codebook is still the one the search saw: the EMA update comes last
         r["quantized"], r["loss_partial"], r["n_partial"] = gather_project(z, E, r["indices"], project, ws)
     N = r["N"]
-    counts = ws.get("counts", K * 4, torch.int32)
+    counts = ws.get("counts", K * 4, torch.int32)[:K]
     histogram(r["idx32"][:N], K, ws, out=counts)
     loss, perp, _ = step_scalars(r["loss_partial"], r["n_partial"], N, D, beta,
                                  counts if stats_reduce is None else None, K, z.device)
@@ -544,7 +544,7 @@ def _empty_step(z, E, ema_w, cluster_size, usage, decay, epsilon, training, ws, 
         shape[1] = project.shape[1]
     q = torch.empty(shape, dtype=torch.float32, device=dev)
     nan = torch.full((), float("nan"), dtype=torch.float32, device=dev)
-    counts = ws.get("counts", K * 4, torch.int32)
+    counts = ws.get("counts", K * 4, torch.int32)[:K]
     counts.zero_()
     if training:
         dw = ws.get("dw", K * D * 4, torch.float32)[: K * D].view(K, D)
