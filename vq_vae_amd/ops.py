@@ -163,6 +163,9 @@ def search(z: torch.Tensor, E: torch.Tensor, ws: Workspace, temperature: float =
     plain fp32 search elsewhere.
 
     Returns dict(indices int64 [N], idx32, dmin|None, quantized|None, loss_partial|None, n_partial).
+    ``indices``, ``dmin`` and ``quantized`` are fresh tensors; ``idx32`` and ``loss_partial`` are views of
+    buffers in ``ws`` that the next search on the same workspace overwrites (they feed the histogram,
+    scatter and scalar kernels of the same step) -- clone them to keep them.
     """
     lib = _lib.load()
     if z.dtype != torch.float32:
