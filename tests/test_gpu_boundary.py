@@ -171,6 +171,9 @@ def test_dict_output_and_state_dict(dev):
     ((1, 16, 1, 1), 8, False),            # a single row, no bias
     ((700, 128), 96, True),               # rows (what a channels_last tensor is in memory)
     ((300, 32), 33, False),               # output width not a multiple of 4: scalar stores
+    ((700, 128), 128, True),              # rows, every output tile full (the kernel with the counted stage wait), ragged rows
+    ((2, 64, 5, 7), 64, False),           # the same kernel in NCHW with ragged rows
+    ((5, 32, 16, 16), 192, True),         # three full stages
 ])
 def test_conv1x1_kernel(shape, c_out, bias, dev):
     """vq_conv1x1 against a float64 evaluation of nn.Conv2d(C, O, 1) (vqvae/custom_vqgan.py:50-51) and

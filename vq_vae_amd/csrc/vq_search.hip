@@ -487,6 +487,25 @@ __device__ __forceinline__ void conv_store_tile(const f32x16& c, int code0, int 
   }
 }
 
+// The same store when every output channel of the tile exists (C_out a multiple of 64): no
+// predicate anywhere, so the number of store instructions per tile is fixed (16 in NCHW, 4 in rows).
+template <bool NCHW>
+__device__ __forceinline__ void conv_store_full(const f32x16& c, int code0, int h, float* obase, int64_t cstride) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int d0 = code0 + 8 * q + 4 * h;
+    if (!NCHW) {
+      f32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = c[4 * q + r];
+      *reinterpret_cast<f32x4*>(obase + d0) = o;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) obase[(int64_t)(d0 + r) * cstride] = c[4 * q + r];
+    }
+  }
+}
+
 template <int D, bool NCHW>
 __global__ __launch_bounds__(512, 2) void vq_conv1x1_kernel(ConvArgs a) {
   constexpr int NW = 8;
@@ -587,21 +606,134 @@ __global__ __launch_bounds__(512, 2) void vq_conv1x1_kernel(ConvArgs a) {
   conv_store_tile<NCHW>(cB, (a.nstages - 1) * VQ_STAGE_CODES + 32, h, a.Cout, valid, obase, cstride);
 }
 
+template <int D, bool NCHW>
+__global__ __launch_bounds__(512, 2) void vq_conv1x1_full_kernel(ConvArgs a) {
+  constexpr int NW = 8;
+  constexpr int S = D / 2;
+  constexpr int G = D / 8;
+  constexpr int STAGE_F = VQ_STAGE_CODES * D + 256;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int64_t row0 = (int64_t)blockIdx.x * VQ_WG_ROWS + wave * 32;
+
+  stage_copy<D, NW>(a.image, 0, lds, wave, lane);
+
+  // x tile into registers in B-operand order: xr[s] = x[row][2s + h]
+  float xr[S];
+  int64_t n = row0 + j;
+  const bool valid = n < a.N;
+  if (!valid) n = a.N - 1;
+  float* obase;
+  int64_t cstride;
+  if (NCHW) {
+    const int64_t b = n / a.HW, hw = n - b * a.HW;
+    const float* src = a.x + (b * D + h) * a.HW + hw;
+    const int64_t xstride = 2 * a.HW;
+#pragma unroll
+    for (int s = 0; s < S; ++s) xr[s] = src[(int64_t)s * xstride];
+    obase = a.out + b * a.Cout * a.HW + hw;
+    cstride = a.HW;
+  } else {
+    // (dword loads: a 16-byte load would hold four registers to leave two, and the tile fills the file)
+    const float* src = a.x + n * D + h;
+#pragma unroll
+    for (int m = 0; m < D / 4; ++m) {
+      xr[2 * m] = src[4 * m];
+      xr[2 * m + 1] = src[4 * m + 2];
+    }
+    obase = a.out + n * a.Cout;
+    cstride = 1;
+  }
+
+  f32x16 cA, cB;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) cB[i] = 0.0f;
+
+  __syncthreads();
+
+  int cur = 0;
+  for (int st = 0; st < a.nstages; ++st) {
+    float* buf = lds + cur * STAGE_F;
+    if (st + 1 < a.nstages) stage_copy<D, NW>(a.image, st + 1, lds + (cur ^ 1) * STAGE_F, wave, lane);
+    const f32x4* A = reinterpret_cast<const f32x4*>(buf) + lane;
+    const f32x4* bs = reinterpret_cast<const f32x4*>(buf + VQ_STAGE_CODES * D) + h;
+
+    // first half: output channels [64 st, 64 st + 32) into set A, starting from their bias;
+    // store set B of stage st-1
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 b4 = bs[2 * q];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cA[4 * q + r] = b4[r];
+    }
+    {
+      f32x4 af = A[0];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const f32x4 an = A[(g + 1 < G ? g + 1 : g) * 64];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cA = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], xr[4 * g + q], cA, 0, 0, 0);
+        af = an;
+      }
+    }
+    if (st > 0) conv_store_full<NCHW>(cB, (st - 1) * VQ_STAGE_CODES + 32, h, obase, cstride);
+
+    // second half: output channels [64 st + 32, 64 st + 64) into set B; store set A
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 b4 = bs[8 + 2 * q];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cB[4 * q + r] = b4[r];
+    }
+    {
+      f32x4 af = A[G * 64];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const f32x4 an = A[(G + (g + 1 < G ? g + 1 : g)) * 64];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cB = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], xr[4 * g + q], cB, 0, 0, 0);
+        af = an;
+      }
+    }
+    conv_store_full<NCHW>(cA, st * VQ_STAGE_CODES, h, obase, cstride);
+
+    // The barrier must see this wave's DMA of stage st+1 landed, not its stores: vector memory
+    // operations retire in issue order, and exactly STORES_PER_TILE (first stage) or twice that many
+    // stores were issued after the DMA, so waiting for all but those is enough.
+    constexpr int SPT = NCHW ? 16 : 4;
+    if (st == 0) __builtin_amdgcn_s_waitcnt(((SPT & 15) | ((SPT >> 4) << 14)) | 0x0F70);
+    else __builtin_amdgcn_s_waitcnt((((2 * SPT) & 15) | (((2 * SPT) >> 4) << 14)) | 0x0F70);
+    __builtin_amdgcn_s_barrier();
+    cur ^= 1;
+  }
+  conv_store_full<NCHW>(cB, (a.nstages - 1) * VQ_STAGE_CODES + 32, h, obase, cstride);
+}
+
 template <int D>
 int launch_conv(const ConvArgs& a, bool nchw, hipStream_t s) {
   const size_t lds_bytes = 2 * vq_stage_floats(D) * 4 + 256;
-  static bool attr_done[2][64] = {};
+  // every output channel of every tile exists: the kernel whose stage barrier waits for the DMA only
+  const bool full = a.Cout % VQ_STAGE_CODES == 0;
+  const void* kern = full ? (nchw ? reinterpret_cast<const void*>(vq_conv1x1_full_kernel<D, true>)
+                                  : reinterpret_cast<const void*>(vq_conv1x1_full_kernel<D, false>))
+                          : (nchw ? reinterpret_cast<const void*>(vq_conv1x1_kernel<D, true>)
+                                  : reinterpret_cast<const void*>(vq_conv1x1_kernel<D, false>));
+  static bool attr_done[2][2][64] = {};
   int dev = 0;
   VQ_CHECK_HIP(hipGetDevice(&dev));
-  const void* kern = nchw ? reinterpret_cast<const void*>(vq_conv1x1_kernel<D, true>)
-                          : reinterpret_cast<const void*>(vq_conv1x1_kernel<D, false>);
-  if (!attr_done[nchw][dev & 63]) {
+  if (!attr_done[full][nchw][dev & 63]) {
     VQ_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    attr_done[nchw][dev & 63] = true;
+    attr_done[full][nchw][dev & 63] = true;
   }
   const int64_t blocks = (a.N + VQ_WG_ROWS - 1) / VQ_WG_ROWS;
-  if (nchw) hipLaunchKernelGGL((vq_conv1x1_kernel<D, true>), dim3((unsigned)blocks), dim3(512), lds_bytes, s, a);
-  else hipLaunchKernelGGL((vq_conv1x1_kernel<D, false>), dim3((unsigned)blocks), dim3(512), lds_bytes, s, a);
+  const dim3 grid((unsigned)blocks), block(512);
+  if (full && nchw) hipLaunchKernelGGL((vq_conv1x1_full_kernel<D, true>), grid, block, lds_bytes, s, a);
+  else if (full) hipLaunchKernelGGL((vq_conv1x1_full_kernel<D, false>), grid, block, lds_bytes, s, a);
+  else if (nchw) hipLaunchKernelGGL((vq_conv1x1_kernel<D, true>), grid, block, lds_bytes, s, a);
+  else hipLaunchKernelGGL((vq_conv1x1_kernel<D, false>), grid, block, lds_bytes, s, a);
   return vq_hip_status(hipGetLastError());
 }
 
