@@ -250,9 +250,47 @@ def g10():
                                         stats["normalized_entropy"], stats["total_usage"]], np.float64))
 
 
+def g11():
+    """The call pattern of VQGANTrainer on the quantizer (vqvae/vqgan_trainer.py): per epoch
+    reset_dead_codes(threshold=2, current_epoch) in training mode (:339; nothing is dead enough in
+    this data, so it returns 0 -- the return value is stored), then per batch one forward under
+    torch.no_grad() (discriminator step, :86) and one with gradients (generator step, :136) --
+    both in training mode, so the EMA update runs twice per batch -- a backward through
+    quantized and loss, and get_codebook_stats() as CustomVQGAN.forward(return_dict=True) calls it
+    (vqvae/custom_vqgan.py:102).  T = 2.5 as in vqvae/improved_vq_config.py:60."""
+    K, D, T = 64, 16, 2.5
+    E = gauss(1102, (K, D)) * np.float32(0.6)
+    q = make_ref(K, D, 10.0, 0.7, E)
+    q.train(True)
+    rec = {"E0": E, "T": np.float32(T), "beta": np.float32(10.0), "decay": np.float64(0.7)}
+    step = 0
+    for epoch in (1, 2):
+        rec[f"e{epoch}_reset"] = np.int64(q.reset_dead_codes(threshold=2, current_epoch=epoch))
+        for b in range(2):
+            z = gauss(1110 + step, (2, D, 4, 4))
+            w = gauss(1130 + step, (2, D, 4, 4))
+            with torch.no_grad():
+                o1 = run_step(q, z, T)
+            zt = torch.from_numpy(z).requires_grad_(True)
+            quant, loss, (perp, idx, _enc) = q(zt, temperature=T)
+            ((quant * torch.from_numpy(w)).sum() + loss).backward()
+            st = q.get_codebook_stats()
+            rec[f"s{step}_idx_nograd"] = o1["indices"]
+            rec[f"s{step}_idx"] = idx.numpy().astype(np.int64).copy()
+            rec[f"s{step}_loss"] = np.float32(loss.item())
+            rec[f"s{step}_perplexity"] = np.float32(perp.item())
+            rec[f"s{step}_grad"] = zt.grad.numpy().copy()
+            rec[f"s{step}_stats"] = np.array([st["active_size"], st["utilization"], st["entropy"],
+                                              st["normalized_entropy"], st["total_usage"]], np.float64)
+            for k, v in state_of(q).items():
+                rec[f"s{step}_{k}"] = v
+            step += 1
+    np.savez_compressed(os.path.join(HERE, "g11_trainer_pattern.npz"), **rec)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g6, g8, g9, g10):
+    for fn in (g1, g2, g3, g4, g6, g8, g9, g10, g11):
         if not only or fn.__name__ in only:
             fn()
     total = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))

@@ -328,3 +328,37 @@ def test_empty_batch_behaves_like_the_reference(training, dev):
         fresh.train()
         fresh(torch.zeros(0, D, 2, 2, device=dev))
         assert torch.isnan(fresh.embedding.weight).all() and float(fresh.ema_cluster_size.abs().sum()) == 0
+
+
+def test_trainer_call_pattern_matches_reference(dev):
+    """g11: what VQGANTrainer does to the quantizer (vqvae/vqgan_trainer.py:339, :86, :136;
+    vqvae/custom_vqgan.py:102) -- reset_dead_codes per epoch, per batch one forward under no_grad and one
+    with gradients, both in training mode (two EMA updates per batch), backward, get_codebook_stats --
+    on the GPU module against the reference's own outputs."""
+    g = np.load(os.path.join(GOLDEN, "g11_trainer_pattern.npz"))
+    K, D = g["E0"].shape
+    m = make(K, D, float(g["beta"]), float(g["decay"]), g["E0"], dev)
+    m.train()
+    T = float(g["T"])
+    step = 0
+    for epoch in (1, 2):
+        assert m.reset_dead_codes(threshold=2, current_epoch=epoch) == int(g[f"e{epoch}_reset"])
+        for b in range(2):
+            z = gauss(1110 + step, (2, D, 4, 4))
+            w = torch.from_numpy(gauss(1130 + step, (2, D, 4, 4))).to(dev)
+            with torch.no_grad():
+                _, _, (_, idx1, _) = m(torch.from_numpy(z).to(dev), temperature=T)
+            zt = torch.from_numpy(z).to(dev).requires_grad_(True)
+            quant, loss, (perp, idx, enc) = m(zt, temperature=T)
+            ((quant * w).sum() + loss).backward()
+            st = m.get_codebook_stats()
+            assert np.array_equal(idx1.cpu().numpy().reshape(-1), g[f"s{step}_idx_nograd"].reshape(-1))
+            assert np.array_equal(idx.cpu().numpy().reshape(-1), g[f"s{step}_idx"].reshape(-1))
+            assert abs(loss.item() - float(g[f"s{step}_loss"])) <= 1e-5 * float(g[f"s{step}_loss"])
+            assert abs(perp.item() - float(g[f"s{step}_perplexity"])) <= 1e-5 * float(g[f"s{step}_perplexity"])
+            assert rel_err(zt.grad.cpu().numpy(), g[f"s{step}_grad"]) <= 1e-5
+            got = np.array([st["active_size"], st["utilization"], st["entropy"], st["normalized_entropy"], st["total_usage"]])
+            assert np.allclose(got, g[f"s{step}_stats"], rtol=1e-5, atol=0)
+            for k, v in m.state_dict().items():
+                assert rel_err(v.cpu().numpy(), g[f"s{step}_state_" + k.replace(".", "_")]) <= 1e-5, k
+            step += 1

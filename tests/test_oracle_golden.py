@@ -201,3 +201,25 @@ def test_oracle_is_clean_under_address_and_ub_sanitizers(tmp_path):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:verify_asan_link_order=0", OMP_NUM_THREADS="4")
     run = subprocess.run([os.path.join(odir, "asan_check")], capture_output=True, text=True, env=env, timeout=300)
     assert run.returncode == 0 and "asan_check ok" in run.stdout, run.stderr[-2000:]
+
+
+def test_trainer_call_pattern(golden_dir):
+    """g11: the trainer's use of the quantizer -- two training-mode forwards per batch (the first
+    under no_grad), so two EMA updates per batch, T = 2.5, decay 0.7 -- replayed through the oracle."""
+    g = np.load(os.path.join(golden_dir, "g11_trainer_pattern.npz"))
+    st = vo.OracleState.fresh(g["E0"])
+    beta, decay, T = float(g["beta"]), float(g["decay"]), float(g["T"])
+    for step in range(4):
+        z = gauss(1110 + step, (2, 16, 4, 4))
+        o1 = vo.forward(z, st, beta, decay, 1e-5, T, True)
+        assert np.array_equal(o1["indices"].reshape(-1), g[f"s{step}_idx_nograd"].reshape(-1))
+        o2 = vo.forward(z, st, beta, decay, 1e-5, T, True)
+        assert np.array_equal(o2["indices"].reshape(-1), g[f"s{step}_idx"].reshape(-1))
+        assert abs(o2["loss"] - g[f"s{step}_loss"]) <= 1e-5 * abs(g[f"s{step}_loss"])
+        assert abs(o2["perplexity"] - g[f"s{step}_perplexity"]) <= 1e-5 * g[f"s{step}_perplexity"]
+        assert rel_err(st.embedding, g[f"s{step}_state_embedding_weight"]) <= 1e-5
+        assert rel_err(st.ema_cluster_size, g[f"s{step}_state_ema_cluster_size"]) <= 1e-5
+        assert np.array_equal(st.usage_count, g[f"s{step}_state_usage_count"])
+        cs = vo.cluster_stats(st.ema_cluster_size, st.usage_count)
+        ref = g[f"s{step}_stats"]
+        assert cs["active_size"] == int(ref[0]) and abs(cs["entropy"] - ref[2]) <= 1e-5 * ref[2] and cs["total_usage"] == ref[4]
