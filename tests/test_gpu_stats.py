@@ -268,3 +268,39 @@ def test_interpolation_smoothness(dev):
     assert abs(r["code_switches"] - switches.mean()) <= 1e-12
     qerr = ((z.reshape(P, steps + 1, D).astype(np.float64) - q) ** 2).sum(2).mean(1)
     assert abs(r["quantization_error"] - qerr.mean()) <= 1e-6 * qerr.mean()
+
+
+def test_monitor_codebook_follows_the_trainer(dev):
+    """stats.monitor_codebook against the decisions of VQGANTrainer.monitor_codebook
+    (vqvae/vqgan_trainer.py:577-650): batch statistics equal the literal torch expressions, the
+    codebook grows by 25 % (capped) once the cumulative utilisation exceeds the threshold, the
+    low-usage reset runs for epochs > 0 under the module's own epoch spacing."""
+    from vq_vae_amd import EMAVectorQuantizer, stats
+    K, D = 64, 16
+    m = EMAVectorQuantizer(K, D, 3.0).to(dev)
+    with torch.no_grad():
+        m.embedding.weight.copy_(torch.from_numpy(gauss(1601, (K, D)) * np.float32(0.5)))
+    m.train()
+    z = torch.from_numpy(gauss(1602, (4, D, 8, 8))).to(dev)
+    _, _, (_, idx, _) = m(z)
+    rep = {}
+    calls = []
+    ne = stats.monitor_codebook(m, idx, 0, max_codebook_size=100, report=rep, on_expand=calls.append, verbose=False)
+    tb = torch_batch_stats(idx.cpu().numpy().reshape(-1), K)
+    assert rep["batch"]["unique"] == tb["unique"] and abs(rep["batch"]["entropy"] - tb["entropy"]) <= 2e-5 * tb["entropy"]
+    # Laplace smoothing makes every cluster size positive after one step: utilisation 1.0 > 0.8 -> expansion
+    assert rep["cumulative"]["utilization"] == 1.0 and rep["expanded_to"] == 80 and m.num_embeddings == 80
+    assert calls == [m] and m.embedding.weight.shape == (80, D) and m.ema_w.shape == (80, D)
+    assert rep["reset_count"] == 0                                   # epoch 0: no reset (:641)
+    assert abs(ne - rep["cumulative"]["normalized_entropy"]) == 0
+    # the module still runs after the expansion, and the next call is capped at the maximum
+    _, _, (_, idx, _) = m(z)
+    stats.monitor_codebook(m, idx, 1, max_codebook_size=100, report=rep, verbose=False)
+    assert m.num_embeddings == 100 and rep["expanded_to"] == 100
+    stats.monitor_codebook(m, idx, 2, max_codebook_size=100, report=rep, verbose=False)
+    assert m.num_embeddings == 100 and rep["expanded_to"] is None
+    # resets are spaced five epochs apart by the module (vqvae/ema_vector_quantizer.py:245-246)
+    stats.monitor_codebook(m, idx, 6, max_codebook_size=100, report=rep, verbose=False)
+    assert rep["reset_count"] == 10
+    stats.monitor_codebook(m, None, 7, disable_codebook_expansion=True, report=rep, verbose=False)
+    assert rep["batch"] is None and rep["reset_count"] == 0

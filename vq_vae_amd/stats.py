@@ -4,6 +4,7 @@ code indices, without host round trips per code.
 * ``CodeUsage`` / ``analyze_indices``: vqvae/codebook_utilization_check.py:83-108 (float64).
 * ``batch_code_stats``: vqvae/vqgan_trainer.py:594-612 (fp32).
 * ``count_used_codes``: vqvae/trainers/vqtrainer.py:59-75 (search + number of distinct codes).
+* ``monitor_codebook``: the trainer's epoch-end check, vqvae/vqgan_trainer.py:577-650.
 * ``pairwise_codebook_stats``: the codebook-distance analysis the reference's README.md:26-29
   describes (the reference holds no code for it; the definition is this package's).
 """
@@ -181,6 +182,56 @@ def analyze_codebook_utilization(quantizer, latent_batches, temperature: float =
     if acc is None:
         raise ValueError("latent_batches was empty")
     return acc.result()
+
+
+def monitor_codebook(quantizer, last_batch_indices: Optional[torch.Tensor], epoch: int, *,
+                     max_codebook_size: int = 512, expansion_threshold: float = 0.8,
+                     disable_codebook_expansion: bool = False, reset_low_usage_percentage: float = 0.1,
+                     on_expand=None, report: Optional[dict] = None, verbose: bool = True) -> float:
+    """The epoch-end codebook check of the reference's trainer (``VQGANTrainer.monitor_codebook``,
+    vqvae/vqgan_trainer.py:577-650) for a quantizer on the GPU, with the reference's decisions and
+    defaults (:62-63: at most 512 codes, expand above 80 % utilisation):
+
+    * cumulative statistics from ``get_codebook_stats()`` (:580);
+    * utilisation and entropy of the last batch's indices (:594-612) -- one histogram kernel and one
+      statistics kernel instead of a loop over the codes with a host copy each (:602-603); pass the
+      index output of the forward (``perplexity_info[1]``), not the one-hot matrix the reference's model
+      hands its trainer;
+    * ``expand_codebook`` by 25 % when the cumulative utilisation exceeds the threshold (:622-636);
+      ``on_expand(quantizer)`` is called after a successful expansion (the reference rebuilds its
+      optimiser there, :636);
+    * ``reset_low_usage_codes`` for epochs > 0 (:641-647).
+
+    Returns the cumulative normalised entropy, as the reference does (:650); ``report`` (a dict), when
+    given, receives everything that the reference prints."""
+    st = quantizer.get_codebook_stats()
+    K = quantizer.num_embeddings
+    info = {"epoch": epoch, "cumulative": st, "batch": None, "expanded_to": None, "reset_count": 0}
+    if last_batch_indices is not None and last_batch_indices.numel() > 0:
+        info["batch"] = batch_code_stats(last_batch_indices.reshape(-1), K)
+    if (not disable_codebook_expansion and st["utilization"] > expansion_threshold and K < max_codebook_size):
+        new_size = min(int(K * 1.25), max_codebook_size)
+        if new_size > K and quantizer.expand_codebook(new_size):
+            info["expanded_to"] = new_size
+            if on_expand is not None:
+                on_expand(quantizer)
+    if epoch > 0:
+        info["reset_count"] = quantizer.reset_low_usage_codes(percentage=reset_low_usage_percentage,
+                                                              current_epoch=epoch)
+    if verbose:
+        print(f"codebook (epoch {epoch}): active {st['active_size']}/{K} ({st['utilization'] * 100:.1f}%), entropy "
+              f"{st['entropy']:.4f} (normalised {st['normalized_entropy']:.4f}), total usage {st['total_usage']:.0f}")
+        if info["batch"] is not None:
+            b = info["batch"]
+            print(f"  last batch: {b['unique']}/{K} codes ({b['utilization'] * 100:.1f}%), entropy {b['entropy']:.4f} "
+                  f"(normalised {b['normalized_entropy']:.4f})")
+        if info["expanded_to"]:
+            print(f"  codebook expanded from {K} to {info['expanded_to']}")
+        if info["reset_count"]:
+            print(f"  {info['reset_count']} low-usage codes re-seeded")
+    if report is not None:
+        report.update(info)
+    return st["normalized_entropy"]
 
 
 def stats_to_json_dict(results: dict) -> dict:
