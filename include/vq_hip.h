@@ -258,6 +258,21 @@ int vq_conv1x1(const float* x, int layout, int64_t N, int C_in, int64_t HW, cons
                void* stream);
 
 /*
+ * Parameter gradients of that convolution:  dW[o][i] = sum_n gy[n][o] x[n][i],  db[o] = sum_n gy[n][o]
+ * (db may be NULL).  ref: autograd of the nn.Conv2d(.., 1) layers of vqvae/custom_vqgan.py:50-51, whose
+ * parameters the reference's optimiser updates (vqvae/vqgan_trainer.py:98-104).  gy and x share one
+ * layout: NCHW (HW a multiple of 32) or rows (channel counts multiples of 4); up to 1024 channels
+ * each; gy, x, work 16-byte aligned.  fp32 MFMA products, partial sums of disjoint row ranges added
+ * in a fixed order: the result is the same bits on every run, and equals the sum over n up to fp32
+ * rounding of the summation order.  `work`: vq_conv1x1_wgrad_work_bytes bytes.
+ * vq_conv1x1_wgrad_supported returns 1 for the shapes the kernel takes.
+ */
+int vq_conv1x1_wgrad_supported(int layout, int64_t N, int C_out, int C_in, int64_t HW);
+int64_t vq_conv1x1_wgrad_work_bytes(int64_t N, int C_out, int C_in);
+int vq_conv1x1_wgrad(const float* gy, const float* x, int layout, int64_t N, int C_out, int C_in, int64_t HW,
+                     float* dW, float* db, void* work, void* stream);
+
+/*
  * Re-seed codes in place (maintenance).  ref: the per-code loops of
  * vqvae/ema_vector_quantizer.py:185-196 (reset_dead_codes: noise 0.2, scale 0.1), :262-274
  * (reset_low_usage_codes: noise 0.4, scale 0.2) and the new rows of :131-148 (expand_codebook:

@@ -224,3 +224,55 @@ def test_conv1x1_autograd_equals_torch_conv(dev):
     assert rel_err(x2.grad.cpu().numpy(), x1.grad.cpu().numpy()) <= 2e-6
     assert rel_err(conv.weight.grad.cpu().numpy(), gw.cpu().numpy()) <= 1e-5
     assert rel_err(conv.bias.grad.cpu().numpy(), gb.cpu().numpy()) <= 1e-5
+
+
+WGRAD_SHAPES = [
+    # (B, C_out, C_in, H, W, channels_last)
+    (2, 256, 256, 8, 8, False),      # two stages per image
+    (3, 256, 256, 16, 16, False),
+    (1, 64, 256, 4, 8, False),       # one stage; output channels clamp inside the 256-block
+    (2, 256, 32, 8, 4, False),
+    (2, 96, 40, 8, 8, False),        # channel counts that are not multiples of 32
+    (2, 320, 272, 8, 4, False),      # more than one 256-block each way
+    (2, 256, 256, 8, 8, True),
+    (1, 64, 128, 5, 7, True),        # 35 rows: a partial last stage
+    (3, 100, 36, 3, 3, True),
+    (67, 256, 256, 32, 32, False),   # more stages than workgroups along the rows
+]
+
+
+@pytest.mark.parametrize("B,O,C,H,W,cl", WGRAD_SHAPES)
+def test_conv1x1_wgrad_kernel(B, O, C, H, W, cl, dev):
+    """dW and db of a 1x1 convolution against the fp64 sums (the parameter gradients autograd gives the
+    reference's quant_conv, vqvae/custom_vqgan.py:50); fp32 tolerance for the order of summation, and
+    the same bits on a second call."""
+    from vq_vae_amd import ops
+    g = torch.Generator(device=dev).manual_seed(B * 1000 + O + C)
+    x = torch.randn(B, C, H, W, device=dev, generator=g)
+    gy = torch.randn(B, O, H, W, device=dev, generator=g)
+    if cl:
+        x = x.contiguous(memory_format=torch.channels_last)
+        gy = gy.contiguous(memory_format=torch.channels_last)
+    ws = ops.Workspace(dev)
+    assert ops.conv1x1_wgrad_supported(gy, x)
+    dW, db = ops.conv1x1_wgrad(gy, x, ws)
+    X = x.permute(0, 2, 3, 1).reshape(-1, C).double()
+    G = gy.permute(0, 2, 3, 1).reshape(-1, O).double()
+    want_W, want_b = G.t() @ X, G.sum(0)
+    n = X.shape[0]
+    tol = 4e-6 * n ** 0.5 + 1e-5
+    assert (dW.double() - want_W).abs().max().item() <= tol * max(1.0, want_W.abs().max().item() / n ** 0.5)
+    assert (db.double() - want_b).abs().max().item() <= tol * max(1.0, want_b.abs().max().item() / n ** 0.5)
+    dW2, db2 = ops.conv1x1_wgrad(gy, x, ws)
+    assert torch.equal(dW, dW2) and torch.equal(db, db2)
+    dW3, none = ops.conv1x1_wgrad(gy, x, ws, want_bias=False)
+    assert none is None and torch.equal(dW, dW3)
+
+
+def test_conv1x1_wgrad_unsupported_shapes_say_so(dev):
+    from vq_vae_amd import ops
+    x = torch.randn(2, 256, 5, 5, device=dev)        # NCHW with H*W not a multiple of 32
+    gy = torch.randn(2, 256, 5, 5, device=dev)
+    assert not ops.conv1x1_wgrad_supported(gy, x)
+    with pytest.raises(RuntimeError, match="vq_conv1x1_wgrad"):
+        ops.conv1x1_wgrad(gy, x, ops.Workspace(dev))

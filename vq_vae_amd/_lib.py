@@ -66,6 +66,10 @@ SIGNATURES = {
     "vq_conv1x1_image_bytes": (c_size_t, [c_int, c_int]),
     "vq_conv1x1_prep": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "vq_conv1x1": (c_int, [c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
+    "vq_conv1x1_wgrad_supported": (c_int, [c_int, c_int64, c_int, c_int, c_int64]),
+    "vq_conv1x1_wgrad_work_bytes": (c_int64, [c_int64, c_int, c_int]),
+    "vq_conv1x1_wgrad": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int64, c_void_p, c_void_p,
+                                 c_void_p, c_void_p]),
     "vq_reseed_stage_bytes": (c_size_t, [c_int, c_int]),
     "vq_reseed_codes": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
                                 c_float, c_float, ctypes.c_uint64, c_void_p, c_void_p]),

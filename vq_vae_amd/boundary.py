@@ -85,8 +85,8 @@ class _QuantizeProjectFn(torch.autograd.Function):
 class _Conv1x1Fn(torch.autograd.Function):
     """A 1x1 convolution (vqvae/custom_vqgan.py:50, applied at :68) whose forward and input gradient
     run on the search's MFMA engine (``vq_conv1x1``: the weights stream through LDS like a 256-row
-    codebook); the weight gradient, a reduction over all N rows, stays with torch's convolution
-    backward."""
+    codebook) and whose weight and bias gradients, sums over all N rows, are ``vq_conv1x1_wgrad``
+    (torch's convolution backward only for shapes that kernel does not take)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, ws):
@@ -107,10 +107,19 @@ class _Conv1x1Fn(torch.autograd.Function):
                 grad_x = ops.conv1x1(go, Wt, None, ctx.ws, "quant_conv_t_image")
             else:
                 grad_x = F.conv2d(go, Wt.reshape(C, O, 1, 1))
-        if ctx.needs_input_grad[1]:
-            grad_w = torch.nn.grad.conv2d_weight(x.float(), weight.shape, go).to(weight.dtype)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            grad_b = go.sum((0, 2, 3))
+        want_w = ctx.needs_input_grad[1]
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if (want_w or want_b) and ops.conv1x1_wgrad_supported(go, x):
+            dW, db = ops.conv1x1_wgrad(go, x, ctx.ws, want_bias=want_b)
+            if want_w:
+                grad_w = dW.reshape(weight.shape).to(weight.dtype)
+            if want_b:
+                grad_b = db
+        else:
+            if want_w:
+                grad_w = torch.nn.grad.conv2d_weight(x.float(), weight.shape, go).to(weight.dtype)
+            if want_b:
+                grad_b = go.sum((0, 2, 3))
         return grad_x, grad_w, grad_b, None
 
 

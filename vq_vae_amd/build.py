@@ -14,7 +14,8 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libvqhip.so")
-SOURCES = ["vq_search.hip", "vq_filter.hip", "vq_ema.hip", "vq_scatter_sorted.hip", "vq_stats.hip", "vq_boundary.hip"]
+SOURCES = ["vq_search.hip", "vq_filter.hip", "vq_ema.hip", "vq_scatter_sorted.hip", "vq_stats.hip", "vq_boundary.hip",
+           "vq_conv_wgrad.hip"]
 HEADERS = [os.path.join(CSRC, "vq_common.h"), os.path.join(os.path.dirname(PKG), "include", "vq_hip.h")]
 # -ffp-contract=off: the kernels spell out every fused multiply-add they want; nothing else may fuse,
 # or the distances would stop matching the documented rounding.

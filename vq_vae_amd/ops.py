@@ -477,6 +477,51 @@ def conv1x1(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
     return out
 
 
+def conv1x1_wgrad_supported(gy: torch.Tensor, x: torch.Tensor) -> bool:
+    """Shapes vq_conv1x1_wgrad covers: fp32 GPU tensors of one shape family -- (B, C, H, W) with H*W a
+    multiple of 32 in NCHW memory order, or channels_last / (N, C) rows with channel counts that are
+    multiples of 4 -- and at most 1024 channels each."""
+    if not (gy.is_cuda and x.is_cuda and gy.dim() == x.dim() and gy.dim() in (2, 4)):
+        return False
+    if gy.shape[0] != x.shape[0] or gy.shape[2:] != x.shape[2:] or gy.numel() == 0 or x.numel() == 0:
+        return False
+    c_out, c_in = gy.shape[1], x.shape[1]
+    rows_x, _ = _rows_view(x)
+    if gy.dim() == 2 or rows_x is not None:
+        layout, N, HW = LAYOUT_ND, x.numel() // c_in, 1
+    else:
+        layout, N, HW = LAYOUT_NCHW, x.numel() // c_in, x.shape[2] * x.shape[3]
+    return bool(_lib.load().vq_conv1x1_wgrad_supported(layout, N, c_out, c_in, HW))
+
+
+def conv1x1_wgrad(gy: torch.Tensor, x: torch.Tensor, ws: Workspace, want_bias: bool = True):
+    """Parameter gradients of a 1x1 convolution y = W x + b (vqvae/custom_vqgan.py:50-51 under autograd):
+    returns ``(dW, db)`` with dW[o, i] = sum_n gy[n, o] x[n, i] of shape (C_out, C_in) and
+    db[o] = sum_n gy[n, o] (None unless ``want_bias``).  gy and x: (B, C, H, W) or (N, C) rows; a
+    channels_last x is read in place as rows and gy is brought to the same order."""
+    lib = _lib.load()
+    _require_cuda(gy, "grad_output")
+    _require_cuda(x, "input")
+    if not conv1x1_wgrad_supported(gy, x):
+        raise RuntimeError(f"vq_conv1x1_wgrad does not take grad_output {tuple(gy.shape)} with input {tuple(x.shape)}")
+    c_out, c_in = gy.shape[1], x.shape[1]
+    rows_x, _ = _rows_view(x)
+    if rows_x is not None:
+        x2 = _f32c(rows_x, "input")
+        g2 = gy.float().contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(-1, c_out)
+        layout, N, HW = LAYOUT_ND, x2.shape[0], 1
+    else:
+        x2 = _f32c(x, "input")
+        g2 = _f32c(gy, "grad_output")
+        layout, N, HW = _shape_of(x2, c_in)
+    work = ws.get("wgrad_work", lib.vq_conv1x1_wgrad_work_bytes(N, c_out, c_in), torch.float32)
+    dW = torch.empty((c_out, c_in), dtype=torch.float32, device=x.device)
+    db = torch.empty((c_out,), dtype=torch.float32, device=x.device) if want_bias else None
+    check(lib.vq_conv1x1_wgrad(_ptr(g2), _ptr(x2), layout, N, c_out, c_in, HW, _ptr(dW), _ptr(db), _ptr(work),
+                               _stream(x.device)), "vq_conv1x1_wgrad")
+    return dW, db
+
+
 def quantize_step(z: torch.Tensor, E: torch.Tensor, ema_w, cluster_size, usage, *, beta: float, decay: float,
                   epsilon: float, temperature: float, training: bool, ws: Workspace, want_dmin: bool = False,
                   stats_reduce=None, search_events=None, filtered: bool = False,
