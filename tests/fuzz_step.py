@@ -3,7 +3,7 @@
 sizes, channel counts (inside and outside the matrix-core set), batch shapes, layouts (NCHW, channels_last,
 rows), temperatures and value scales; two steps per problem.  Prints one line per failure and a summary.
 
-    python tools/fuzz_step.py [trials] [seed]
+    python tests/fuzz_step.py [trials] [seed]
 """
 import os
 import sys
