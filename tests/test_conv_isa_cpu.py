@@ -57,3 +57,44 @@ def test_counted_waits_match_the_stores_behind_the_dma(assembly):
             assert k >= 0 and stores == n, f"{name}: vmcnt({n}) guards a barrier with {stores} stores behind the DMA"
             seen += 1
         assert seen >= 2, f"{name}: expected the first-stage and the steady-state counted waits, found {seen}"
+
+
+def test_weights_stationary_kernel_counts_three_tiles_behind(assembly):
+    """vq_conv1x1_ws_kernel waits, before the barrier that opens a tile, for all vector memory operations but
+    those issued behind the tile's own DMA: the stores of three tiles and the DMA instructions of two.
+    Per instantiation: the counted wait equals 3 x (stores per tile) + 2 x (DMA instructions per tile) as
+    the compiler emitted them, and no other vector memory operation follows the first barrier."""
+    kernels = re.findall(r"^(_ZN\S*vq_conv1x1_ws_kernel\S*):\s*(?:;.*)?$", assembly, re.M)
+    assert len(kernels) == 6, kernels           # 3 channel counts x 2 layouts
+    for name in kernels:
+        start = assembly.index(name + ":")
+        body = assembly[start: assembly.index(".end_amdhsa_kernel", start)]
+        ops = [l.split() for l in (x.strip() for x in body.split("\n")) if l and not l.startswith((";", "."))]
+        groups, waits, seen_barrier = [], [], False
+        for n_op, op in enumerate(ops):
+            kind = None
+            if op[0].startswith("global_load_lds"):
+                kind = "dma"
+            elif op[0].startswith("global_store"):
+                kind = "store"
+            elif op[0].startswith(("global_", "buffer_", "flat_", "scratch_")):
+                assert not seen_barrier, f"{name}: {op[0]} after the first barrier"
+                kind = "other"
+                waits.clear()                   # waits so far belong to the prologue (weights, bias)
+            elif op[0] == "s_barrier":
+                seen_barrier = True
+            elif op[0] == "s_waitcnt":
+                m = re.search(r"vmcnt\((\d+)\)", " ".join(op))
+                if m and int(m.group(1)) > 0:
+                    waits.append(int(m.group(1)))   # counted waits behind the prologue's loads: the loop's
+            if kind is None:
+                if op[0].startswith(("s_cbranch", "s_branch", "s_barrier")) or op[0] == "s_waitcnt":
+                    groups.append(None)         # a group ends at control flow, a wait or a barrier
+                continue
+            if groups and groups[-1] is not None and groups[-1][0] == kind:
+                groups[-1][1] += 1
+            else:
+                groups.append([kind, 1])
+        dma = min(g[1] for g in groups if g and g[0] == "dma")
+        stores = min(g[1] for g in groups if g and g[0] == "store")
+        assert waits and all(w == 3 * stores + 2 * dma for w in waits), (name, waits, stores, dma)

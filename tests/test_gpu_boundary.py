@@ -205,6 +205,45 @@ def test_conv1x1_kernel(shape, c_out, bias, dev):
     assert torch.isnan(bad).any() and (torch.isfinite(bad).any() or bad.numel() == c_out)
 
 
+@pytest.mark.parametrize("shape,c_out,bias", [
+    ((36, 256, 32, 32), 256, True),       # 36 Ki rows: the weights-stationary kernel, NCHW and channels_last
+    ((40, 64, 32, 32), 512, True),        # two 256-channel blocks of outputs
+    ((130, 128, 16, 16), 256, False),     # images of 256 pixels, no bias
+    ((33001, 128), 256, True),            # rows with a ragged last tile
+    ((65, 256, 32, 32), 256, True),       # more tiles than one round of the ring per workgroup
+])
+def test_conv1x1_weights_stationary_kernel(shape, c_out, bias, dev):
+    """Batches of 32 Ki rows and more with whole 256-channel output blocks run the persistent
+    weights-stationary kernel: against float64, bit-equal across layouts, and bit-equal to the
+    streamed-weights kernel that a small batch of the same rows runs."""
+    from inputs import gauss
+    from vq_vae_amd import ops
+    c_in = shape[1]
+    x = gauss(1301, shape)
+    W = gauss(1302, (c_out, c_in)) * np.float32(0.3)
+    b = gauss(1303, (c_out,)) if bias else None
+    ws = ops.Workspace(dev)
+    xt, Wt = torch.from_numpy(x).to(dev), torch.from_numpy(W).to(dev)
+    bt = None if b is None else torch.from_numpy(b).to(dev)
+    got = ops.conv1x1(xt, Wt, bt, ws)
+    rows = xt.permute(0, 2, 3, 1).reshape(-1, c_in) if xt.dim() == 4 else xt
+    want = rows.double() @ Wt.double().t() + (0 if bt is None else bt.double())
+    grow = got.permute(0, 2, 3, 1).reshape(-1, c_out) if got.dim() == 4 else got
+    assert got.shape[:2] == (shape[0], c_out)
+    assert ((grow.double() - want).abs().max() / want.abs().max()).item() <= 2e-6
+    small = ops.conv1x1(xt[:7].contiguous(), Wt, bt, ws)         # 7 images / 7 rows: the streamed-weights kernel
+    assert torch.equal(small, got[:7])
+    last = ops.conv1x1(xt[-5:].contiguous(), Wt, bt, ws)
+    assert torch.equal(last, got[-5:])
+    if xt.dim() == 4:
+        cl = ops.conv1x1(xt.contiguous(memory_format=torch.channels_last), Wt, bt, ws)
+        assert torch.equal(cl.contiguous(), got)
+    xb = xt.clone()
+    xb.view(-1)[11] = float("nan")
+    bad = ops.conv1x1(xb, Wt, bt, ws)
+    assert torch.isnan(bad).any() and torch.isfinite(bad).any()
+
+
 def test_conv1x1_autograd_equals_torch_conv(dev):
     """The boundary's quant_conv through vq_conv1x1 (forward and input gradient) against nn.Conv2d."""
     from inputs import gauss

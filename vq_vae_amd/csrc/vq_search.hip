@@ -712,8 +712,197 @@ __global__ __launch_bounds__(512, 2) void vq_conv1x1_full_kernel(ConvArgs a) {
   conv_store_full<NCHW>(cB, (a.nstages - 1) * VQ_STAGE_CODES + 32, h, obase, cstride);
 }
 
+// ---------------------------------------------------------------------------------------
+// The same convolution, weights stationary: for C_out a multiple of 256.
+//
+// A persistent workgroup of 8 waves keeps a 256 x D block of W in registers for the whole launch --
+// wave w the A fragments of output channels [32 w, 32 w + 32), D/2 registers per lane, read once
+// from the image -- and the rows stream past it: tiles of 32 rows (32 x D floats) go through a ring
+// of four LDS slots, copied by LDS-DMA three tiles ahead, every wave multiplies its 32 channels into
+// each tile and stores the finished 32 x 32 block (the SIMD's other wave keeps the pipe busy meanwhile).  Loads and stores
+// are then two even streams instead of a burst of row loads before each sweep and a burst of stores
+// after it.  The chain of an output is unchanged (input channels in increasing order, started from
+// the bias), so the result is the same bits as the kernels above.
+//   NCHW: a slot is [channel][32 pixels]; lane (j, h) reads pixel j of channel 2s + h with
+//         ds_read_b32, the 32 lanes of a half on 32 different banks.
+//   rows: a slot is [row][D], channel c of row r at position c ^ r (r < 32) so that the 32 rows a
+//         half reads for one k-step lie on 32 different banks; the DMA writes LDS linearly, so the
+//         permutation is applied on the source side, one dword per lane.
+// A wave's stage wait is counted: behind the DMA of the tile it is about to read lie exactly three
+// tiles' stores and two tiles' DMA instructions.
+// ---------------------------------------------------------------------------------------
+template <int D, bool NCHW>
+struct WsPlan {
+  static constexpr int RING = 4;
+  static constexpr int AHEAD = 3;
+  static constexpr int TILE_F = 32 * D;
+  static constexpr int DMA_PER_WAVE = NCHW ? D / 64 : D / 16;   // 1 KiB (16 B per lane) / 256 B (4 B per lane) pieces
+  static constexpr int SPT = NCHW ? 16 : 4;                     // store instructions per finished tile
+  static constexpr int BEHIND = 3 * SPT + 2 * DMA_PER_WAVE;
+};
+
+template <int D, bool NCHW>
+__device__ __forceinline__ void ws_tile_copy(const ConvArgs& a, int64_t tile, float* slot, int wave, int lane) {
+  using P = WsPlan<D, NCHW>;
+  char* dst = reinterpret_cast<char*>(slot);
+  if (NCHW) {
+    const int64_t row0 = tile * 32;
+    const int64_t img = row0 / a.HW, hw0 = row0 - img * a.HW;
+    const float* base = a.x + img * D * a.HW + hw0 + 4 * (lane & 7);
+#pragma unroll
+    for (int k = 0; k < P::DMA_PER_WAVE; ++k) {
+      const int p = wave + 8 * k;                 // channels [8p, 8p + 8)
+      const float* g = base + (int64_t)(8 * p + (lane >> 3)) * a.HW;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
+    }
+  } else {
+    constexpr int SEG = D / 64;                   // 64-position pieces per row
+#pragma unroll
+    for (int k = 0; k < P::DMA_PER_WAVE; ++k) {
+      const int p = wave + 8 * k;
+      const int r = p / SEG, q = p % SEG;
+      int64_t n = tile * 32 + r;
+      n = n < a.N ? n : a.N - 1;
+      const float* g = a.x + n * D + ((64 * q + lane) ^ r);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(dst + (r * D + 64 * q) * 4), 4, 0, 0);
+    }
+  }
+}
+
+// One tile: acc = bias (from LDS), then the D/2 k-steps against the slot in chunks of eight, the B
+// values of the next chunk in flight under the MFMAs of this one.  Nothing moves across a chunk's
+// end, which bounds the registers the LDS reads may occupy.
+template <int D, bool NCHW>
+__device__ __forceinline__ void ws_tile_mfma(f32x16& acc, const f32x4* bias4, const float (&wr)[D / 2],
+                                             const float* slot, int j, int h) {
+  constexpr int CH = D / 16;                 // chunks of 8 k-steps
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 v = bias4[2 * q];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[4 * q + r] = v[r];
+  }
+  const char* sb = reinterpret_cast<const char*>(slot);
+  // NCHW: pixel j of channel 2s + h.  rows: channel 2s + h of row j sits at position (2s + h) ^ j;
+  // the low five bits carry the permutation, the rest of s is an immediate.
+  const char* nb = sb + (NCHW ? (h * 32 + j) * 4 : j * D * 4);
+  float bc[8], bn[8];
+  auto load = [&](float (&b)[8], int c) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int s = 8 * c + q;
+      if (NCHW) b[q] = *reinterpret_cast<const float*>(nb + s * 256);
+      else b[q] = *reinterpret_cast<const float*>(nb + (((2 * (s & 15) + h) ^ j) * 4) + (s >> 4) * 128);
+    }
+  };
+  load(bc, 0);
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    if (c + 1 < CH) load(bn, c + 1);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[8 * c + q], bc[q], acc, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) bc[q] = bn[q];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int D, bool NCHW>
+__global__ __launch_bounds__(512, 1) void vq_conv1x1_ws_kernel(ConvArgs a, int64_t ntiles) {
+  using P = WsPlan<D, NCHW>;
+  constexpr int G = D / 8;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* lds_bias = lds + P::RING * P::TILE_F;      // 256 floats
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int otile = 8 * blockIdx.y + wave;          // 32 output channels
+  const int64_t first = blockIdx.x, step = gridDim.x;
+  const int64_t cnt = (ntiles - first + step - 1) / step;    // tiles of this workgroup (>= 1: grid.x <= ntiles)
+
+  // the first tiles are on their way while the weights load
+#pragma unroll
+  for (int i = 0; i < P::AHEAD; ++i)
+    ws_tile_copy<D, NCHW>(a, first + (i < cnt ? i : cnt - 1) * step, lds + i * P::TILE_F, wave, lane);
+
+  // weights: piece g of the tile holds, for this lane, the A values of k-steps 4g .. 4g + 3
+  float wr[D / 2];
+  {
+    const float* st = a.image + (size_t)(otile >> 1) * vq_stage_floats(D);
+    const f32x4* wp = reinterpret_cast<const f32x4*>(st) + (size_t)(otile & 1) * G * 64 + lane;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const f32x4 v = wp[g * 64];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wr[4 * g + q] = v[q];
+    }
+    if (lane < 32) lds_bias[32 * wave + lane] = st[VQ_STAGE_CODES * D + 32 * (otile & 1) + lane];
+  }
+  const f32x4* bias4 = reinterpret_cast<const f32x4*>(lds_bias + 32 * wave) + h;   // [2q]: rows 8q + 4h ..
+
+  f32x16 acc;
+  const int64_t cstride = NCHW ? a.HW : 1;
+
+  for (int64_t ii = 0; ii < cnt; ++ii) {
+    // this wave's share of tile ii has landed once all but the operations issued behind it are done:
+    // the stores of three tiles and the DMA instructions of two
+    if (ii >= 3) __builtin_amdgcn_s_waitcnt(((P::BEHIND & 15) | ((P::BEHIND >> 4) << 14)) | 0x0F70);
+    else __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_s_barrier();
+    {
+      const int64_t nx = ii + P::AHEAD;
+      ws_tile_copy<D, NCHW>(a, first + (nx < cnt ? nx : cnt - 1) * step, lds + (int)(nx & 3) * P::TILE_F, wave, lane);
+    }
+    ws_tile_mfma<D, NCHW>(acc, bias4, wr, lds + (int)(ii & 3) * P::TILE_F, j, h);
+    const int64_t tile = first + ii * step;
+    float* ob;
+    if (NCHW) {
+      const int64_t row0 = tile * 32;
+      const int64_t img = row0 / a.HW, hw0 = row0 - img * a.HW;
+      ob = a.out + img * a.Cout * a.HW + hw0 + j;
+    } else {
+      int64_t n = tile * 32 + j;
+      n = n < a.N ? n : a.N - 1;
+      ob = a.out + n * a.Cout;
+    }
+    conv_store_full<NCHW>(acc, 32 * otile, h, ob, cstride);
+  }
+}
+
+template <int D>
+int launch_conv_ws(const ConvArgs& a, bool nchw, hipStream_t s) {
+  const size_t lds_bytes = (size_t)4 * 32 * D * 4 + 1024;
+  const void* kern = nchw ? reinterpret_cast<const void*>(vq_conv1x1_ws_kernel<D, true>)
+                          : reinterpret_cast<const void*>(vq_conv1x1_ws_kernel<D, false>);
+  static bool attr_done[2][64] = {};
+  static int cus[64] = {};
+  int dev = 0;
+  VQ_CHECK_HIP(hipGetDevice(&dev));
+  if (!attr_done[nchw][dev & 63]) {
+    VQ_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    attr_done[nchw][dev & 63] = true;
+  }
+  if (!cus[dev & 63]) VQ_CHECK_HIP(hipDeviceGetAttribute(&cus[dev & 63], hipDeviceAttributeMultiprocessorCount, dev));
+  const int64_t ntiles = (a.N + 31) / 32;
+  const int gy = a.Cout / 256;
+  int64_t gx = cus[dev & 63] / gy;
+  if (gx < 1) gx = 1;
+  if (gx > ntiles) gx = ntiles;
+  const dim3 grid((unsigned)gx, (unsigned)gy), block(512);
+  if (nchw) hipLaunchKernelGGL((vq_conv1x1_ws_kernel<D, true>), grid, block, lds_bytes, s, a, ntiles);
+  else hipLaunchKernelGGL((vq_conv1x1_ws_kernel<D, false>), grid, block, lds_bytes, s, a, ntiles);
+  return vq_hip_status(hipGetLastError());
+}
+
 template <int D>
 int launch_conv(const ConvArgs& a, bool nchw, hipStream_t s) {
+  // whole 256-channel blocks of outputs, whole 32-row tiles per image, enough tiles for the ring to pay
+  if constexpr (D >= 64) {
+    if (a.Cout % 256 == 0 && (!nchw || a.HW % 32 == 0) && a.N >= 32 * 1024) return launch_conv_ws<D>(a, nchw, s);
+  }
   const size_t lds_bytes = 2 * vq_stage_floats(D) * 4 + 256;
   // every output channel of every tile exists: the kernel whose stage barrier waits for the DMA only
   const bool full = a.Cout % VQ_STAGE_CODES == 0;
