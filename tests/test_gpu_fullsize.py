@@ -65,3 +65,45 @@ def test_full_size_properties():
     assert torch.equal(E3, E) and torch.equal(w3, ema_w) and torch.equal(c3, cs) and torch.equal(u3, usage)
     assert abs(outf.loss.item() - out.loss.item()) <= 1e-6 * abs(out.loss.item())
     assert torch.equal(outf.perplexity, out.perplexity)
+
+
+def test_full_size_boundary_convolutions():
+    """The 1x1 convolutions either side of the quantizer at the benchmark's batch (4 Mi rows, 256 -> 256
+    channels): vq_conv1x1 against float64 on sampled rows and bit-equal across layouts; vq_conv1x1_wgrad
+    against float64 sums for a few output channels, equal across layouts to fp32 rounding, and its bias
+    gradient against the column sums."""
+    assert torch.cuda.is_available()
+    from vq_vae_amd import ops
+    dev = torch.device("cuda:0")
+    C, B, H = 256, 4096, 32
+    N = B * H * H
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn(B, C, H, H, device=dev, generator=g)
+    W = torch.randn(C, C, device=dev, generator=g) * 0.06
+    b = torch.randn(C, device=dev, generator=g)
+    ws = ops.Workspace(dev)
+    y = ops.conv1x1(x, W, b, ws)
+    rows = torch.randint(0, N, (4096,), device=dev, generator=g)
+    xs = x.permute(0, 2, 3, 1).reshape(N, C)[rows].double()
+    want = xs @ W.double().t() + b.double()
+    got = y.permute(0, 2, 3, 1).reshape(N, C)[rows].double()
+    assert ((got - want).abs().max() / want.abs().max()).item() <= 2e-6
+    x_cl = x.contiguous(memory_format=torch.channels_last)
+    y_cl = ops.conv1x1(x_cl, W, b, ws)
+    assert torch.equal(y_cl, y)                       # same values, whatever the strides
+    del y_cl
+    # parameter gradients with y as the incoming gradient
+    dW, db = ops.conv1x1_wgrad(y, x, ws)
+    want_w = torch.zeros(4, C, dtype=torch.float64, device=dev)
+    for b0 in range(0, B, 256):
+        X = x[b0:b0 + 256].permute(0, 2, 3, 1).reshape(-1, C).double()
+        G = y[b0:b0 + 256, :4].permute(0, 2, 3, 1).reshape(-1, 4).double()
+        want_w += G.t() @ X
+    assert ((dW[:4].double() - want_w).abs().max() / want_w.abs().max()).item() <= 1e-5
+    want_b = y.double().sum(dim=(0, 2, 3))
+    assert ((db.double() - want_b).abs().max() / want_b.abs().max()).item() <= 1e-5
+    dW_cl, db_cl = ops.conv1x1_wgrad(y.contiguous(memory_format=torch.channels_last), x_cl, ws)
+    assert ((dW_cl - dW).abs().max() / dW.abs().max()).item() <= 1e-5
+    assert ((db_cl - db).abs().max() / db.abs().max()).item() <= 1e-5
+    dW2, db2 = ops.conv1x1_wgrad(y, x, ws)
+    assert torch.equal(dW2, dW) and torch.equal(db2, db)      # fixed order of the partial sums
