@@ -1,0 +1,47 @@
+"""Hardware probe behind the convolution kernels' counted waits (tests/hip/vmcnt_probe.hip): a wave's
+vector memory operations leave the vmcnt counter in issue order even when LDS-DMA loads and global
+stores are mixed, so `s_waitcnt vmcnt(n)` with n stores issued behind a DMA waits for that DMA."""
+import ctypes
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def probe():
+    path = os.path.join(HERE, "hip", "libvmcnt_probe.so")
+    if not os.path.exists(path):
+        sys.path.insert(0, os.path.join(HERE, "hip"))
+        import build_probe
+        build_probe.build()
+    lib = ctypes.CDLL(path)
+    lib.vmcnt_probe_fill.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+    lib.vmcnt_probe.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int,
+                                ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    return lib
+
+
+def test_stores_do_not_overtake_an_older_dma(probe):
+    dev = torch.device("cuda:0")
+    words = 1 << 29                                     # 2 GiB: every DMA is a miss all the way to HBM
+    src = torch.empty(words, dtype=torch.int32, device=dev)
+    blocks, iters = 8192, 128
+    hot = torch.zeros(blocks * 64, dtype=torch.int32, device=dev)
+    stale = torch.zeros(3, dtype=torch.int32, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    assert probe.vmcnt_probe_fill(src.data_ptr(), words, s) == 0
+    for mode in (0, 1, 2):
+        rc = probe.vmcnt_probe(mode, src.data_ptr(), words, hot.data_ptr(), blocks, iters,
+                               stale.data_ptr() + 4 * mode, s)
+        assert rc == 0
+    torch.cuda.synchronize()
+    counted, short, deep = (int(v) for v in stale.cpu())
+    # a wait one operation short of the DMA reads the slot before the DMA has landed: the probe can see lateness
+    assert short > 0
+    # the kernels' waits (16 stores behind the DMA; 56, the largest count in use): never a stale slot
+    assert counted == 0 and deep == 0, (counted, deep, short)
