@@ -9,12 +9,19 @@ executed on CPU; nothing of its source is stored, only inputs and outputs.  All 
 from seeded NumPy PCG64 streams (helpers in tests/golden/inputs.py) so the tests can
 regenerate the large ones instead of storing them.
 
-Not generated here: the dict output of CustomVQGAN and analyze_codebook_utilization /
-monitor_codebook -- their modules import diffusers / torchvision, which this image lacks.
+Two more reference functions run here although their modules cannot be imported in this image
+(vqvae/codebook_utilization_check.py and vqvae/vqgan_trainer.py import torchvision / diffusers at
+module level): analyze_codebook_utilization and VQGANTrainer.monitor_codebook use neither, so
+`reference_function` compiles just that one definition out of the reference file's syntax tree
+(read from /root/reference at run time) and g12 / g13 call it with small stand-in *arguments* (a
+model object that returns given indices; a trainer namespace around the real reference quantizer).
+Not generated: the dict output of CustomVQGAN (its constructor needs diffusers' encoder / decoder).
 """
+import ast
 import hashlib
 import os
 import sys
+import types
 
 import numpy as np
 import torch
@@ -288,9 +295,132 @@ def g11():
     np.savez_compressed(os.path.join(HERE, "g11_trainer_pattern.npz"), **rec)
 
 
+def reference_function(rel_path, name, namespace):
+    """The function (or method) `name` of the reference file, compiled on its own from the file's
+    syntax tree and bound in `namespace` (which supplies the globals its body uses)."""
+    path = os.path.join("/root/reference", rel_path)
+    with open(path, encoding="utf-8") as f:
+        tree = ast.parse(f.read(), filename=path)
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and node.name == name:
+            mod = ast.Module(body=[node], type_ignores=[])
+            exec(compile(mod, path, "exec"), namespace)
+            return namespace[name]
+    raise KeyError(name)
+
+
+def locals_at_return(fn, *args, **kwargs):
+    """Call fn and return (result, its local variables at the moment it returned)."""
+    seen = {}
+
+    def prof(frame, event, arg):
+        if event == "return" and frame.f_code is fn.__code__:
+            seen.update(frame.f_locals)
+
+    sys.setprofile(prof)
+    try:
+        out = fn(*args, **kwargs)
+    finally:
+        sys.setprofile(None)
+    return out, seen
+
+
+def index_cases():
+    """Index streams for the statistics: (name, K, int64 indices)."""
+    rng = np.random.Generator(np.random.PCG64(1200))
+    cases = [("uniform", 64, rng.integers(0, 64, 5000)),
+             ("single", 64, np.full(777, 13)),
+             ("all_once", 64, rng.permutation(64)),
+             ("half", 64, rng.integers(0, 32, 3000)),
+             ("wide", 512, rng.integers(0, 512, 4096))]
+    w = 1.0 / np.arange(1, 65) ** 1.1
+    cases.append(("zipf", 64, rng.choice(64, 6000, p=w / w.sum())))
+    return [(n, k, np.asarray(i, np.int64)) for n, k, i in cases]
+
+
+def g12():
+    """analyze_codebook_utilization (vqvae/codebook_utilization_check.py:64-120), the reference's own
+    function, on index streams handed to it by a stand-in model: its "indices" output is whatever the
+    batch holds, so the function's statistics (:83-108) run on known indices."""
+    from tqdm import tqdm
+    fn = reference_function("vqvae/codebook_utilization_check.py", "analyze_codebook_utilization",
+                            {"torch": torch, "np": np, "tqdm": lambda it, **kw: it})
+    del tqdm
+
+    class Model:
+        def __init__(self, K):
+            self.quantize = types.SimpleNamespace(num_embeddings=K)
+
+        def eval(self):
+            return self
+
+        def __call__(self, images, return_dict=True, temperature=1.0):
+            return {"indices": images}
+
+    rec = {}
+    for name, K, idx in index_cases():
+        batches = [(torch.from_numpy(part), None) for part in np.array_split(idx, 3)]
+        r = fn(Model(K), batches, torch.device("cpu"))
+        rec[f"{name}_K"] = np.int64(K)
+        rec[f"{name}_indices"] = idx
+        rec[f"{name}_unique"] = np.asarray(r["unique_indices"], np.int64)
+        rec[f"{name}_scalars"] = np.array([r["utilization"], r["entropy"], r["normalized_entropy"], r["gini"]],
+                                          np.float64)
+        rec[f"{name}_index_counts"] = np.asarray(r["index_counts"], np.float64)
+        rec[f"{name}_probs"] = np.asarray(r["probs"], np.float64)
+    np.savez_compressed(os.path.join(HERE, "g12_utilization_reference.npz"), **rec)
+
+
+def g13():
+    """VQGANTrainer.monitor_codebook (vqvae/vqgan_trainer.py:577-650), the reference's own method, called
+    on a namespace that holds what it reads: the reference quantizer after three training steps, the
+    last batch's indices and the trainer's settings.  Stored: the quantizer's state before the call,
+    the values the method computed (its locals when it returned) and what it decided -- the contents
+    of re-seeded / new rows are random in the reference and are not stored."""
+    fn = reference_function("vqvae/vqgan_trainer.py", "monitor_codebook", {"torch": torch, "print": lambda *a, **k: None})
+    K, D = 64, 16
+    rec = {}
+    cases = [("plain", 0, True, 0.8, 512, 0.1, 0.6),         # epoch 0: statistics only
+             ("expand", 7, False, 0.5, 96, 0.1, 0.6),        # utilisation above the threshold: 64 -> 80, then 8 re-seeded
+             ("reset", 6, True, 0.8, 512, 0.25, 0.6),        # five epochs since the last re-seeding: 16 codes
+             ("capped", 2, False, 0.5, 70, 0.25, 0.6),       # expansion capped by the maximum size: 64 -> 70
+             ("collapsed", 4, False, 0.8, 512, 0.1, 0.02)]   # a codebook the data does not use: no expansion
+    for name, epoch, disabled, thr, max_size, pct, scale in cases:
+        E = gauss(1300, (K, D)) * np.float32(scale)
+        q = make_ref(K, D, 3.0, 0.95, E)
+        q.train(True)
+        idx = None
+        for step in range(3):
+            z = gauss(1310 + step, (2, D, 8, 8))
+            with torch.no_grad():
+                idx = run_step(q, z, 1.0)["indices"]
+        for k, v in state_of(q).items():
+            rec[f"{name}_{k}"] = v
+        trainer = types.SimpleNamespace(
+            vqgan=types.SimpleNamespace(quantize=q), last_batch_indices=torch.from_numpy(idx).flatten(),
+            disable_codebook_expansion=disabled, expansion_threshold=thr, max_codebook_size=max_size,
+            reset_low_usage_percentage=pct, _update_optimizers_after_expansion=lambda: None)
+        torch.manual_seed(5)
+        out, loc = locals_at_return(fn, trainer, epoch)
+        rec[f"{name}_args"] = np.array([epoch, int(disabled), thr, max_size, pct], np.float64)
+        rec[f"{name}_last_batch_indices"] = idx.reshape(-1)
+        rec[f"{name}_returned"] = np.float64(out)
+        rec[f"{name}_batch"] = np.array([len(loc["unique_indices"]), loc["real_utilization"], loc["batch_entropy"],
+                                         loc["batch_norm_entropy"]], np.float64)
+        st = loc["stats"]
+        rec[f"{name}_cumulative"] = np.array([st["active_size"], st["utilization"], st["entropy"],
+                                              st["normalized_entropy"], st["total_usage"]], np.float64)
+        rec[f"{name}_size_after"] = np.int64(q.num_embeddings)
+        rec[f"{name}_reset_count"] = np.int64(loc.get("reset_count", 0))
+        rec[f"{name}_last_reset_epoch_after"] = np.int64(q.last_low_usage_reset_epoch.item())
+        rec[f"{name}_state_shapes_after"] = np.array([q.embedding.weight.shape[0], q.ema_w.shape[0],
+                                                      q.ema_cluster_size.shape[0], q.usage_count.shape[0]], np.int64)
+    np.savez_compressed(os.path.join(HERE, "g13_monitor_codebook_reference.npz"), **rec)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g6, g8, g9, g10, g11):
+    for fn in (g1, g2, g3, g4, g6, g8, g9, g10, g11, g12, g13):
         if not only or fn.__name__ in only:
             fn()
     total = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))

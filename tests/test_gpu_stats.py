@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import GOLDEN, rel_err
 from inputs import gauss
 from oracle import vq_oracle as vo
 from test_distributed_cpu import pack_key
@@ -304,3 +304,60 @@ def test_monitor_codebook_follows_the_trainer(dev):
     assert rep["reset_count"] == 10
     stats.monitor_codebook(m, None, 7, disable_codebook_expansion=True, report=rep, verbose=False)
     assert rep["batch"] is None and rep["reset_count"] == 0
+
+
+@pytest.mark.parametrize("case", ["uniform", "single", "all_once", "half", "wide", "zipf"])
+def test_index_statistics_against_the_reference_function(case, dev):
+    """Golden g12 (the reference's analyze_codebook_utilization run on known index streams): the GPU
+    statistics, fed in three batches like the reference's loader."""
+    from vq_vae_amd import stats
+    g = np.load(f"{GOLDEN}/g12_utilization_reference.npz")
+    K, idx = int(g[f"{case}_K"]), g[f"{case}_indices"]
+    acc = stats.CodeUsage(K, dev)
+    for part in np.array_split(idx, 3):
+        acc.update(torch.from_numpy(part).to(dev))
+    r = acc.result()
+    util, ent, nent, gini = g[f"{case}_scalars"]
+    assert r["n_embed"] == K and np.array_equal(np.asarray(r["unique_indices"]), g[f"{case}_unique"])
+    assert np.array_equal(np.asarray(r["index_counts"], np.float64), g[f"{case}_index_counts"])
+    assert r["utilization"] == util
+    assert abs(r["entropy"] - ent) <= 1e-12 * max(1.0, abs(ent)) and abs(r["normalized_entropy"] - nent) <= 1e-12
+    assert abs(r["gini"] - gini) <= 1e-12 * max(1.0, abs(gini))
+    assert np.allclose(np.asarray(r["probs"], np.float64), g[f"{case}_probs"], rtol=0, atol=1e-15)
+
+
+@pytest.mark.parametrize("case", ["plain", "expand", "reset", "capped", "collapsed"])
+def test_monitor_codebook_against_the_reference_method(case, dev):
+    """Golden g13 (the reference's VQGANTrainer.monitor_codebook run on the reference quantizer): the
+    module loaded with the stored state, stats.monitor_codebook with the stored settings -- the same
+    return value, batch and cumulative statistics, codebook size afterwards and number of re-seeded codes."""
+    from vq_vae_amd import EMAVectorQuantizer, stats
+    g = np.load(f"{GOLDEN}/g13_monitor_codebook_reference.npz")
+    E = g[f"{case}_state_embedding_weight"]
+    K, D = E.shape
+    m = EMAVectorQuantizer(K, D, 3.0).to(dev)
+    sd = {"embedding.weight": E, "ema_cluster_size": g[f"{case}_state_ema_cluster_size"], "ema_w": g[f"{case}_state_ema_w"],
+          "usage_count": g[f"{case}_state_usage_count"], "last_reset_epoch": g[f"{case}_state_last_reset_epoch"],
+          "last_low_usage_reset_epoch": g[f"{case}_state_last_low_usage_reset_epoch"]}
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    m.train()
+    epoch, disabled, thr, max_size, pct = g[f"{case}_args"]
+    rep, calls = {}, []
+    out = stats.monitor_codebook(m, torch.from_numpy(g[f"{case}_last_batch_indices"]).to(dev), int(epoch),
+                                 max_codebook_size=int(max_size), expansion_threshold=float(thr),
+                                 disable_codebook_expansion=bool(disabled), reset_low_usage_percentage=float(pct),
+                                 on_expand=calls.append, report=rep, verbose=False)
+    assert abs(out - float(g[f"{case}_returned"])) <= 2e-6
+    wb, wc = g[f"{case}_batch"], g[f"{case}_cumulative"]
+    b, c = rep["batch"], rep["cumulative"]
+    assert b["unique"] == int(wb[0]) and abs(b["utilization"] - wb[1]) <= 1e-7
+    assert abs(b["entropy"] - wb[2]) <= 2e-6 * wb[2] and abs(b["normalized_entropy"] - wb[3]) <= 2e-6
+    assert c["active_size"] == int(wc[0]) and c["utilization"] == wc[1] and c["total_usage"] == wc[4]
+    assert abs(c["entropy"] - wc[2]) <= 2e-6 * wc[2] and abs(c["normalized_entropy"] - wc[3]) <= 2e-6
+    size = int(g[f"{case}_size_after"])
+    assert m.num_embeddings == size and (rep["expanded_to"] == size if size != K else rep["expanded_to"] is None)
+    assert len(calls) == (1 if size != K else 0)
+    assert [m.embedding.weight.shape[0], m.ema_w.shape[0], m.ema_cluster_size.shape[0], m.usage_count.shape[0]] == \
+        list(g[f"{case}_state_shapes_after"])
+    assert rep["reset_count"] == int(g[f"{case}_reset_count"])
+    assert int(m.last_low_usage_reset_epoch.item()) == int(g[f"{case}_last_reset_epoch_after"])

@@ -223,3 +223,56 @@ def test_trainer_call_pattern(golden_dir):
         cs = vo.cluster_stats(st.ema_cluster_size, st.usage_count)
         ref = g[f"s{step}_stats"]
         assert cs["active_size"] == int(ref[0]) and abs(cs["entropy"] - ref[2]) <= 1e-5 * ref[2] and cs["total_usage"] == ref[4]
+
+
+G12_CASES = ["uniform", "single", "all_once", "half", "wide", "zipf"]
+
+
+@pytest.mark.parametrize("case", G12_CASES)
+def test_index_statistics_match_the_reference_function(case):
+    """Golden g12: the reference's own analyze_codebook_utilization (vqvae/codebook_utilization_check.py:64-120)
+    run on known index streams; the oracle's float64 statistics reproduce what it returned."""
+    g = np.load(f"{GOLDEN}/g12_utilization_reference.npz")
+    K, idx = int(g[f"{case}_K"]), g[f"{case}_indices"]
+    counts = vo.histogram(idx, K)
+    assert np.array_equal(counts.astype(np.float64), g[f"{case}_index_counts"])
+    assert np.array_equal(np.flatnonzero(counts), g[f"{case}_unique"])
+    st = vo.index_stats_f64(counts, idx.size)
+    util, ent, nent, gini = g[f"{case}_scalars"]
+    assert st["unique"] == g[f"{case}_unique"].size and st["utilization"] == util
+    assert abs(st["entropy"] - ent) <= 1e-12 * max(1.0, abs(ent))
+    assert abs(st["normalized_entropy"] - nent) <= 1e-12
+    assert abs(st["gini"] - gini) <= 1e-12 * max(1.0, abs(gini))
+    assert np.allclose(counts / idx.size, g[f"{case}_probs"], rtol=0, atol=1e-15)
+
+
+G13_CASES = ["plain", "expand", "reset", "capped", "collapsed"]
+
+
+@pytest.mark.parametrize("case", G13_CASES)
+def test_monitor_codebook_values_match_the_reference_method(case):
+    """Golden g13: the reference's own VQGANTrainer.monitor_codebook (vqvae/vqgan_trainer.py:577-650) on the
+    reference quantizer after three training steps; the oracle's cumulative statistics (fp32, from the
+    stored cluster sizes) and batch statistics (fp32, from the stored last-batch indices) reproduce the
+    values the method computed, and its decisions follow from them as restated here."""
+    g = np.load(f"{GOLDEN}/g13_monitor_codebook_reference.npz")
+    K = g[f"{case}_state_embedding_weight"].shape[0]
+    cum = vo.cluster_stats(g[f"{case}_state_ema_cluster_size"], g[f"{case}_state_usage_count"])
+    want = g[f"{case}_cumulative"]
+    assert cum["active_size"] == int(want[0]) and cum["utilization"] == want[1] and cum["total_usage"] == want[4]
+    assert abs(cum["entropy"] - want[2]) <= 2e-6 * want[2] and abs(cum["normalized_entropy"] - want[3]) <= 2e-6
+    assert abs(float(g[f"{case}_returned"]) - cum["normalized_entropy"]) <= 2e-6
+    idx = g[f"{case}_last_batch_indices"]
+    b = vo.index_stats_f32(vo.histogram(idx, K))
+    wb = g[f"{case}_batch"]
+    assert b["unique"] == int(wb[0]) and abs(b["utilization"] - wb[1]) <= 1e-7
+    assert abs(b["entropy"] - wb[2]) <= 2e-6 * wb[2] and abs(b["normalized_entropy"] - wb[3]) <= 2e-6
+    epoch, disabled, thr, max_size, pct = g[f"{case}_args"]
+    size = K
+    if not disabled and cum["utilization"] > thr and K < max_size:          # :622-634
+        size = max(K, min(int(K * 1.25), int(max_size)))
+    assert size == int(g[f"{case}_size_after"]) and set(g[f"{case}_state_shapes_after"]) == {size}
+    last = int(g[f"{case}_state_last_low_usage_reset_epoch"].reshape(-1)[0])
+    resets = max(1, int(size * pct)) if epoch > 0 and epoch - last >= 5 else 0  # :641, ema_vector_quantizer.py:245-252
+    assert resets == int(g[f"{case}_reset_count"])
+    assert int(g[f"{case}_last_reset_epoch_after"]) == (int(epoch) if resets else last)
