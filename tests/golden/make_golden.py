@@ -13,9 +13,10 @@ Two more reference functions run here although their modules cannot be imported 
 (vqvae/codebook_utilization_check.py and vqvae/vqgan_trainer.py import torchvision / diffusers at
 module level): analyze_codebook_utilization and VQGANTrainer.monitor_codebook use neither, so
 `reference_function` compiles just that one definition out of the reference file's syntax tree
-(read from /root/reference at run time) and g12 / g13 call it with small stand-in *arguments* (a
+(read from /root/reference at run time) and g12 / g13 / g14 (VQModelTrainer.get_perplexity) call it with small stand-in *arguments* (a
 model object that returns given indices; a trainer namespace around the real reference quantizer).
-Not generated: the dict output of CustomVQGAN (its constructor needs diffusers' encoder / decoder).
+CustomVQGAN's constructor needs diffusers' encoder / decoder, but its encode / decode / forward
+methods only call them: g15 binds those three methods to a module with identity encoder / decoder.
 """
 import ast
 import hashlib
@@ -418,9 +419,86 @@ def g13():
     np.savez_compressed(os.path.join(HERE, "g13_monitor_codebook_reference.npz"), **rec)
 
 
+def g14():
+    """VQModelTrainer.get_perplexity (vqvae/trainers/vqtrainer.py:46-82), the reference's own method: the
+    number of distinct nearest codes of an encoder output's latents.  The trainer and the encoder output
+    are namespaces holding what the method reads (model.quantize.embedding / .vq_embed_dim, .latents)."""
+    fn = reference_function("vqvae/trainers/vqtrainer.py", "get_perplexity", {"torch": torch})
+    rec = {}
+    for name, K, D, shape, scale, half in (("small", 64, 16, (2, 16, 8, 8), 0.6, False),
+                                           ("wide", 512, 64, (3, 64, 8, 8), 1.0, False),
+                                           ("collapsed", 128, 32, (2, 32, 8, 8), 0.01, False),
+                                           ("half", 64, 16, (2, 16, 8, 8), 0.6, True)):
+        E = gauss(1400, (K, D)) * np.float32(scale)
+        z = gauss(1401, shape)
+        emb = torch.nn.Embedding(K, D)
+        with torch.no_grad():
+            emb.weight.copy_(torch.from_numpy(E))
+        trainer = types.SimpleNamespace(model=types.SimpleNamespace(quantize=types.SimpleNamespace(embedding=emb, vq_embed_dim=D)))
+        lat = torch.from_numpy(z)
+        if half:
+            lat = lat.half()
+            z = lat.float().numpy()          # the values the method works on after its cast (:59)
+        out = fn(trainer, types.SimpleNamespace(latents=lat))
+        rec[f"{name}_E"] = E
+        rec[f"{name}_latents"] = z
+        rec[f"{name}_used"] = np.int64(out)
+    np.savez_compressed(os.path.join(HERE, "g14_get_perplexity_reference.npz"), **rec)
+
+
+def g15():
+    """CustomVQGAN.encode / .decode / .forward (vqvae/custom_vqgan.py:62-114), the reference's own methods,
+    bound to a module that holds what they read: quant_conv and post_quant_conv as nn.Conv2d(D, D, 1),
+    the reference quantizer, and identity encoder / decoder (the real ones need diffusers and are not
+    on this path).  return_dict=True in training and eval mode, T = 1 and 2.5, and an encoder output of
+    2 D channels (the mean / log-variance form, :66-67); gradients of a * sum(decoded * w) + b * loss."""
+    ns = {"torch": torch}
+    methods = {n: reference_function("vqvae/custom_vqgan.py", n, ns) for n in ("encode", "decode", "forward")}
+    Host = type("Host", (torch.nn.Module,), dict(methods))
+    K, D = 64, 16
+    E = gauss(1502, (K, D)) * np.float32(0.6)
+    Wq = gauss(1504, (D, D, 1, 1)) * np.float32(0.3)
+    bq = gauss(1505, (D,)) * np.float32(0.1)
+    Wp = gauss(1506, (D, D, 1, 1)) * np.float32(0.3)
+    bp = gauss(1507, (D,)) * np.float32(0.1)
+    w = gauss(1503, (2, D, 4, 4))
+    for name, mode, T, channels in (("train", "train", 1.0, D), ("eval", "eval", 1.0, D), ("train_T", "train", 2.5, D),
+                                    ("train_2D", "train", 1.0, 2 * D)):
+        x = gauss(1501, (2, channels, 4, 4))
+        m = Host()
+        m.encoder, m.decoder = torch.nn.Identity(), torch.nn.Identity()
+        m.quantize = make_ref(K, D, 3.0, 0.95, E)
+        m.quant_conv, m.post_quant_conv = torch.nn.Conv2d(D, D, 1), torch.nn.Conv2d(D, D, 1)
+        with torch.no_grad():
+            m.quant_conv.weight.copy_(torch.from_numpy(Wq)); m.quant_conv.bias.copy_(torch.from_numpy(bq))
+            m.post_quant_conv.weight.copy_(torch.from_numpy(Wp)); m.post_quant_conv.bias.copy_(torch.from_numpy(bp))
+        m.train(mode == "train")
+        xt = torch.from_numpy(x).requires_grad_(True)
+        out = m(xt, return_dict=True, temperature=T)
+        assert sorted(out) == ["commitment_loss", "decoded_imgs", "entropy", "indices", "normalized_entropy", "perplexity"]
+        obj = 0.7 * (out["decoded_imgs"] * torch.from_numpy(w)).sum() + 1.3 * out["commitment_loss"]
+        obj.backward()
+        tup = m(torch.from_numpy(x), return_dict=False, temperature=T) if mode == "eval" else None
+        rec = dict(E=E, x=x, w=w, Wq=Wq, bq=bq, Wp=Wp, bp=bp, T=np.float32(T), a=np.float32(0.7), b=np.float32(1.3),
+                   beta=np.float32(3.0), decay=np.float64(0.95),
+                   decoded_imgs=out["decoded_imgs"].detach().numpy().copy(),
+                   commitment_loss=np.float32(out["commitment_loss"].item()),
+                   indices_onehot=out["indices"].detach().numpy().copy(),
+                   perplexity=np.float32(out["perplexity"].item()), entropy=np.float32(out["entropy"].item()),
+                   normalized_entropy=np.float32(out["normalized_entropy"].item()),
+                   grad_x=xt.grad.numpy().copy(), grad_Wq=m.quant_conv.weight.grad.numpy().copy(),
+                   grad_bq=m.quant_conv.bias.grad.numpy().copy(), grad_Wp=m.post_quant_conv.weight.grad.numpy().copy(),
+                   grad_bp=m.post_quant_conv.bias.grad.numpy().copy(), **state_of(m.quantize))
+        if tup is not None:
+            rec["tuple_decoded"] = tup[0].detach().numpy().copy()
+            rec["tuple_loss"] = np.float32(tup[1].item())
+            rec["tuple_perplexity"] = np.float32(tup[2].item())
+        np.savez_compressed(os.path.join(HERE, f"g15_vqgan_forward_{name}.npz"), **rec)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g6, g8, g9, g10, g11, g12, g13):
+    for fn in (g1, g2, g3, g4, g6, g8, g9, g10, g11, g12, g13, g14, g15):
         if not only or fn.__name__ in only:
             fn()
     total = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))

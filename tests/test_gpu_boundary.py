@@ -315,3 +315,42 @@ def test_conv1x1_wgrad_unsupported_shapes_say_so(dev):
     assert not ops.conv1x1_wgrad_supported(gy, x)
     with pytest.raises(RuntimeError, match="vq_conv1x1_wgrad"):
         ops.conv1x1_wgrad(gy, x, ops.Workspace(dev))
+
+
+@pytest.mark.parametrize("case", ["train", "eval", "train_T", "train_2D"])
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_forward_dict_matches_the_reference_vqgan_forward(case, channels_last, dev):
+    """Golden g15: the reference's own CustomVQGAN.forward(return_dict=True) (vqvae/custom_vqgan.py:76-114,
+    with encode :62-69 and decode :71-74, identity encoder / decoder) -- every entry of the dict, the
+    one-hot matrix under "indices" included, the post-step state and all gradients."""
+    g = np.load(f"{GOLDEN}/g15_vqgan_forward_{case}.npz")
+    K, D = g["E"].shape
+    m = make(K, D, float(g["beta"]), float(g["decay"]), g["E"], g["Wq"], g["bq"], g["Wp"], g["bp"], dev)
+    m.train(case != "eval")
+    x = torch.from_numpy(g["x"]).to(dev)
+    if channels_last:
+        x = x.contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
+    out = m.forward_dict(x, temperature=float(g["T"]))
+    assert sorted(out) == ["commitment_loss", "decoder_input", "entropy", "indices", "normalized_entropy", "perplexity"]
+    obj = float(g["a"]) * (out["decoder_input"] * torch.from_numpy(g["w"]).to(dev)).sum() + float(g["b"]) * out["commitment_loss"]
+    obj.backward()
+    torch.cuda.synchronize()
+    enc = out["indices"]
+    enc = enc.materialize() if hasattr(enc, "materialize") else enc
+    assert np.array_equal(enc.cpu().numpy(), g["indices_onehot"])
+    assert rel_err(out["decoder_input"].detach().cpu().numpy(), g["decoded_imgs"]) <= TOL
+    assert abs(out["commitment_loss"].item() - g["commitment_loss"]) <= TOL * abs(g["commitment_loss"])
+    assert abs(out["perplexity"].item() - g["perplexity"]) <= TOL * abs(g["perplexity"])
+    assert abs(out["entropy"].item() - g["entropy"]) <= TOL * abs(g["entropy"])
+    assert abs(out["normalized_entropy"].item() - g["normalized_entropy"]) <= TOL
+    assert rel_err(x.grad.cpu().numpy(), g["grad_x"]) <= TOL
+    assert rel_err(m.quant_conv.weight.grad.cpu().numpy(), g["grad_Wq"]) <= TOL
+    assert rel_err(m.quant_conv.bias.grad.cpu().numpy(), g["grad_bq"]) <= TOL
+    assert rel_err(m.post_quant_conv.weight.grad.cpu().numpy(), g["grad_Wp"]) <= TOL
+    assert rel_err(m.post_quant_conv.bias.grad.cpu().numpy(), g["grad_bp"]) <= TOL
+    sd = m.state_dict()
+    assert rel_err(sd["quantize.embedding.weight"].cpu().numpy(), g["state_embedding_weight"]) <= TOL
+    assert rel_err(sd["quantize.ema_w"].cpu().numpy(), g["state_ema_w"]) <= TOL
+    assert rel_err(sd["quantize.ema_cluster_size"].cpu().numpy(), g["state_ema_cluster_size"]) <= TOL
+    assert np.array_equal(sd["quantize.usage_count"].cpu().numpy(), g["state_usage_count"])

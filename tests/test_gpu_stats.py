@@ -361,3 +361,14 @@ def test_monitor_codebook_against_the_reference_method(case, dev):
         list(g[f"{case}_state_shapes_after"])
     assert rep["reset_count"] == int(g[f"{case}_reset_count"])
     assert int(m.last_low_usage_reset_epoch.item()) == int(g[f"{case}_last_reset_epoch_after"])
+
+
+@pytest.mark.parametrize("case", ["small", "wide", "collapsed", "half"])
+def test_count_used_codes_against_the_reference_method(case, dev):
+    """Golden g14 (the reference's VQModelTrainer.get_perplexity run on stored latents and codebooks)."""
+    from vq_vae_amd import stats
+    g = np.load(f"{GOLDEN}/g14_get_perplexity_reference.npz")
+    z, E = torch.from_numpy(g[f"{case}_latents"]).to(dev), torch.from_numpy(g[f"{case}_E"]).to(dev)
+    if case == "half":
+        z = z.half()                                      # the method casts to float32 itself (:59)
+    assert stats.count_used_codes(z, E) == int(g[f"{case}_used"])

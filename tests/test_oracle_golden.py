@@ -276,3 +276,49 @@ def test_monitor_codebook_values_match_the_reference_method(case):
     resets = max(1, int(size * pct)) if epoch > 0 and epoch - last >= 5 else 0  # :641, ema_vector_quantizer.py:245-252
     assert resets == int(g[f"{case}_reset_count"])
     assert int(g[f"{case}_last_reset_epoch_after"]) == (int(epoch) if resets else last)
+
+
+@pytest.mark.parametrize("case", ["small", "wide", "collapsed", "half"])
+def test_used_code_count_matches_the_reference_method(case):
+    """Golden g14: the reference's own VQModelTrainer.get_perplexity (vqvae/trainers/vqtrainer.py:46-82) --
+    the number of distinct nearest codes of a batch of latents -- against the oracle's search."""
+    g = np.load(f"{GOLDEN}/g14_get_perplexity_reference.npz")
+    z, E = g[f"{case}_latents"], g[f"{case}_E"]
+    rows = np.ascontiguousarray(z.transpose(0, 2, 3, 1).reshape(-1, E.shape[1]))
+    idx, _ = vo.search(rows, E)
+    assert len(np.unique(idx)) == int(g[f"{case}_used"])
+
+
+G15_CASES = ["train", "eval", "train_T", "train_2D"]
+
+
+@pytest.mark.parametrize("case", G15_CASES)
+def test_vqgan_forward_methods(case):
+    """Golden g15: the reference's own CustomVQGAN.encode / .decode / .forward (vqvae/custom_vqgan.py:62-114)
+    around the reference quantizer (identity encoder / decoder): the dict outputs -- with the one-hot
+    matrix under "indices" -- the post-step state and all gradients, against the oracle's composition."""
+    g = load(f"g15_vqgan_forward_{case}.npz")
+    K, D = g["E"].shape
+    x = g["x"]
+    h = x[:, :D] if x.shape[1] == 2 * D else x                     # the mean half of a 2 D encoder output (:66-67)
+    st = vo.OracleState.fresh(g["E"])
+    r = vo.boundary(h, g["Wq"], g["bq"], g["Wp"], g["bp"], st, float(g["beta"]), float(g["decay"]), 1e-5, float(g["T"]),
+                    case != "eval", grad_out=float(g["a"]) * g["w"], grad_loss=float(g["b"]))
+    onehot = g["indices_onehot"]
+    assert onehot.shape == (r["indices"].size, K) and np.array_equal(onehot.sum(1), np.ones(onehot.shape[0]))
+    assert np.array_equal(r["indices"].reshape(-1), onehot.argmax(1))
+    assert rel_err(r["out"], g["decoded_imgs"]) <= TOL
+    assert abs(r["loss"] - g["commitment_loss"]) <= TOL * abs(g["commitment_loss"])
+    assert abs(r["perplexity"] - g["perplexity"]) <= TOL * abs(g["perplexity"])
+    cs = vo.cluster_stats(st.ema_cluster_size, st.usage_count)
+    assert abs(cs["entropy"] - g["entropy"]) <= TOL * abs(g["entropy"])
+    assert abs(cs["normalized_entropy"] - g["normalized_entropy"]) <= TOL
+    gx = g["grad_x"]
+    assert rel_err(r["grad_h"], gx[:, :D]) <= TOL and not gx[:, D:].any()
+    for name in ("grad_Wq", "grad_bq", "grad_Wp", "grad_bp"):
+        assert rel_err(r[name], g[name]) <= TOL, name
+    assert rel_err(st.embedding, g["state_embedding_weight"]) <= TOL
+    assert rel_err(st.ema_w, g["state_ema_w"]) <= TOL
+    assert rel_err(st.ema_cluster_size, g["state_ema_cluster_size"]) <= TOL
+    if case == "eval":
+        assert np.array_equal(g["tuple_decoded"], g["decoded_imgs"]) and g["tuple_loss"] == g["commitment_loss"]
