@@ -209,3 +209,52 @@ def test_sharded_statistics_over_gloo():
         assert merged_idx[K - 3] == 4 and merged_idx[4] == K - 3
         assert mn == P[off].min() and mx == P[off].max()
         assert abs(tot - P[off].sum()) <= 1e-12 * P[off].sum()
+
+
+def _packed_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vq_vae_amd.distributed import make_stats_reduce
+    K, D = 96, 8
+    rng = np.random.Generator(np.random.PCG64(77 + rank))
+    # counts around the split's boundaries and up to the 32-bit range of the histogram's bins
+    c = rng.integers(0, 5000, K).astype(np.uint64)
+    c[:6] = [0, 4095, 4096, 4097, (1 << 31) + 5, (1 << 32) - 1 - rank]
+    c_i32 = torch.from_numpy(c.astype(np.uint32).view(np.int32).copy())
+    dw = torch.from_numpy(rng.standard_normal((K, D)).astype(np.float32))
+    n_local = 1000 + 37 * rank
+    out = {}
+    for name, kw in (("packed", dict(packed=True, uneven_rows=True)), ("plain", dict(packed=False, uneven_rows=True)),
+                     ("packed_even", dict(packed=True)), ("plain_even", dict(packed=False))):
+        c64, dws, n_total = make_stats_reduce(**kw)(c_i32, dw.clone(), n_local)
+        out[name] = (c64.numpy().copy(), dws.numpy().copy(), n_total)
+    q.put((rank, c.copy(), out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_packed_statistics_all_reduce_is_exact():
+    """The one-collective form of the data-parallel hook (dw and the counts, split at 12 bits, in one fp32
+    buffer) against the two-collective form: identical counts over the whole 32-bit range of a bin,
+    identical row totals with uneven batches, bit-identical dw."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_packed_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = (res[0][1] + res[1][1]).astype(np.int64)
+    for _rank, _c, out in res:
+        for name in ("packed", "plain", "packed_even", "plain_even"):
+            assert np.array_equal(out[name][0], want), name
+        assert out["packed"][2] == out["plain"][2] == 1000 + 1037
+        assert out["packed_even"][2] == out["plain_even"][2]
+        assert np.array_equal(out["packed"][1].view(np.uint32), out["plain"][1].view(np.uint32))
+        assert np.array_equal(out["packed_even"][1].view(np.uint32), out["plain"][1].view(np.uint32))
+    assert np.array_equal(res[0][2]["packed"][1].view(np.uint32), res[1][2]["packed"][1].view(np.uint32))

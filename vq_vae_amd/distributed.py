@@ -34,18 +34,48 @@ def _all_reduce(t: torch.Tensor, op, group) -> None:
         dist.all_reduce(t, op=op, group=group)
 
 
-def make_stats_reduce(group: Optional[dist.ProcessGroup] = None, uneven_rows: bool = False):
+def make_stats_reduce(group: Optional[dist.ProcessGroup] = None, uneven_rows: bool = False, packed: bool = True):
     """Returns the ``stats_reduce`` hook of ``ops.quantize_step`` for data-parallel training.
 
-    Two collectives per step: an int64 all-reduce of the K counts (exact for any batch size)
-    and, in training mode, one fp32 all-reduce of dw (K*D*4 bytes: 8 MiB at K=8192, D=256 --
-    launch/latency-bound on xGMI, far below a link's bandwidth).
+    Training mode, ``packed`` (the default): ONE fp32 all-reduce per step over [dw (K*D) | counts low 12
+    bits (K) | counts high bits (K)] -- 8.06 MiB at K=8192, D=256, latency-bound on xGMI, so one
+    collective instead of two is what counts for a per-GPU batch whose whole step takes half a
+    millisecond.  The counts stay exact: a count c travels as c mod 4096 and c div 4096, both sums are
+    integers below 2^24 (up to 4096 ranks and 2^36 rows in total) and fp32 adds such integers
+    exactly; the hook falls back to the two-collective form beyond those limits.
+    Otherwise: an int64 all-reduce of the K counts and, in training mode, an fp32 all-reduce of dw.
     With ``uneven_rows`` the per-rank row counts are summed too (costs a host sync);
     otherwise every rank is assumed to hold the same number of rows.
     """
+    cache = {}
 
     def reduce(counts_i32: torch.Tensor, dw: Optional[torch.Tensor], n_local: int):
         world = dist.get_world_size(group)
+        if packed and dw is not None and world <= 4096 and n_local * world < (1 << 36):
+            K = counts_i32.numel()
+            kd = dw.numel()
+            extra = 2 if uneven_rows else 0
+            key = (dw.device, kd, K, extra)
+            buf = cache.get(key)
+            if buf is None:
+                cache.clear()
+                buf = cache[key] = torch.empty(kd + 2 * K + extra, dtype=torch.float32, device=dw.device)
+            c = counts_to_int64(counts_i32)
+            buf[:kd].copy_(dw.view(-1))
+            buf[kd:kd + K].copy_(c & 4095)
+            buf[kd + K:kd + 2 * K].copy_(c >> 12)
+            if uneven_rows:
+                buf[kd + 2 * K] = float(n_local & 4095)
+                buf[kd + 2 * K + 1] = float(n_local >> 12)
+            _all_reduce(buf, dist.ReduceOp.SUM, group)
+            dw.view(-1).copy_(buf[:kd])
+            counts64 = buf[kd:kd + K].to(torch.int64) + (buf[kd + K:kd + 2 * K].to(torch.int64) << 12)
+            if uneven_rows:
+                tail = buf[kd + 2 * K:].to(torch.int64).cpu()
+                n_total = int(tail[0]) + (int(tail[1]) << 12)
+            else:
+                n_total = n_local * world
+            return counts64, dw, n_total
         if uneven_rows:
             buf = torch.cat([counts_to_int64(counts_i32),
                              torch.tensor([n_local], dtype=torch.int64, device=counts_i32.device)])
