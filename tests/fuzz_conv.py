@@ -31,6 +31,13 @@ def main():
         C = int(rng.choice([16, 32, 64, 128, 256, 4, 12, 36, 40, 272, 520]))
         O = int(rng.choice([1, 3, 4, 31, 32, 33, 64, 96, 100, 128, 256, 257, 320, 512]))
         cl = bool(rng.integers(0, 2))
+        if t % 8 == 7:
+            # a batch large enough for the weights-stationary kernel (32 Ki rows and more, whole
+            # 256-channel output blocks); channels_last with H * W odd gives ragged 32-row tiles
+            C = int(rng.choice([64, 128, 256]))
+            O = int(rng.choice([256, 512]))
+            H, W = (int(rng.choice([16, 32])), 32) if not cl else (int(rng.choice([31, 32, 33])), int(rng.choice([31, 32])))
+            B = -(-32768 // (H * W)) + int(rng.integers(0, 6))
         scale = float(rng.choice([1.0, 1e-3, 30.0]))
         x = torch.randn(B, C, H, W, device=dev, generator=g) * scale
         gy = torch.randn(B, O, H, W, device=dev, generator=g)
