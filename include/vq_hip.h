@@ -48,7 +48,7 @@ size_t vq_norms_bytes(int K);                   /* squared norms of the (padded)
 int64_t vq_search_blocks(int64_t N);            /* workgroups of vq_search = loss partials it writes*/
 size_t vq_loss_partial_bytes(int64_t N);        /* floats: vq_search_blocks(N) + fix-up partials   */
 size_t vq_control_bytes(void);                  /* small block of control words                    */
-size_t vq_search_split_bytes(int64_t N, int K); /* scratch of the small-batch codebook split (0: unused)*/
+size_t vq_search_split_bytes(int64_t N, int K); /* scratch of the codebook split (0: this N, K is not split) */
 int vq_scatter_slabs(int64_t N, int K, int D);  /* number of partial-sum slabs vq_ema_scatter writes (NCHW)*/
 int vq_scatter_slabs_for(int64_t N, int K, int D, int layout, int64_t HW); /* the same for a given layout */
 
@@ -80,9 +80,10 @@ int vq_codebook_prep(const float* E, int K, int D, float* image, float* e2, int3
  *   nf_rows      [N] int32 scratch: rows routed to the exact path (non-finite input)
  *   control      control words (nf counter, codebook flag)
  *   split_ws     vq_search_split_bytes(N, K) bytes of scratch, may be NULL.  With fewer than
- *                32 Ki rows the row tiles alone cannot fill 256 CUs; given this scratch (and
- *                idx64) the codebook sweep is split over extra workgroups and merged, with
- *                identical results.
+ *                32 Ki rows the row tiles alone cannot fill 256 CUs, and up to 512 Ki rows the
+ *                last round of row tiles can leave most of them idle (257 tiles: two rounds);
+ *                given this scratch (and idx64) the codebook sweep is split over extra
+ *                workgroups where that saves time, and merged, with identical results.
  * Ties go to the lowest index; NaN handling follows torch.argmin.
  */
 int vq_search(const float* z, int layout, int64_t N, int D, int64_t HW, const float* E, const float* image,

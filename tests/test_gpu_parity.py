@@ -79,10 +79,13 @@ def test_search_bit_exact(K, D, shape, dev, ops):
 
 
 @pytest.mark.parametrize("K,D,shape", [(8192, 256, (8, 256, 32, 32)), (8192, 256, (3000, 256)),
-                                       (1024, 64, (1, 64, 20, 20)), (8192, 256, (1, 256, 3, 3))])
+                                       (1024, 64, (1, 64, 20, 20)), (8192, 256, (1, 256, 3, 3)),
+                                       (8192, 256, (65, 256, 32, 32)),      # 260 row tiles: eight parts
+                                       (1024, 64, (98304, 64))])            # 384 row tiles: two parts
 def test_small_batch_codebook_split(K, D, shape, dev, ops):
-    """Batches below 32 Ki rows split the codebook sweep over extra workgroups; results must be
-    identical to the unsplit sweep and to the oracle, non-finite rows included."""
+    """Batches below 32 Ki rows, and larger ones whose last round of row tiles would run nearly
+    empty, split the codebook sweep over extra workgroups; results must be identical to the
+    unsplit sweep and to the oracle, non-finite rows included."""
     z = gauss(91, shape)
     E = gauss(92, (K, D)) * np.float32(0.8)
     E[K - 3] = E[5]                                      # duplicate in the last split: lowest index wins
@@ -94,6 +97,8 @@ def test_small_batch_codebook_split(K, D, shape, dev, ops):
         z[7, 9] = np.inf
     ws = ops.Workspace(dev)
     zt, Et = _t(z, dev), _t(E, dev)
+    from vq_vae_amd import _lib
+    assert _lib.load().vq_search_split_bytes(zt.numel() // D, K) > 0         # this shape is split
     a = ops.search(zt, Et, ws, want_quantized=True, want_dmin=True, allow_split=True)
     b = ops.search(zt, Et, ws, want_quantized=True, want_dmin=True, allow_split=False)
     assert torch.equal(a["indices"], b["indices"]) and torch.equal(a["idx32"][: a["N"]], b["idx32"][: b["N"]])

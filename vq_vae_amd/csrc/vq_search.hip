@@ -1378,13 +1378,33 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 }  // namespace
 
-// Codebook split for batches too small to fill the chip: at most 128 row tiles (32 Ki rows), so
-// that row tiles x splits stays within one round of 256 workgroups.
+// Codebook split.  Batches too small to fill the chip -- at most 128 row tiles (32 Ki rows) -- divide
+// the sweep so that row tiles x parts stays within one round of 256 workgroups.  Larger batches
+// (up to 2048 row tiles) divide it in 2, 4 or 8 when their last round of workgroups would run
+// nearly empty: 257 row tiles are two rounds of whole sweeps undivided, but five rounds of quarter
+// sweeps; a division is taken when it saves at least a tenth of the rounds x stages.
 struct SplitPlan { int ksplit; int sps; };
 SplitPlan split_plan(int64_t N, int K) {
+  constexpr int64_t CUS = 256;
   const int64_t blocks = (N + VQ_WG_ROWS - 1) / VQ_WG_ROWS;
   const int nstages = vq_kpad(K) / VQ_STAGE_CODES;
-  if (blocks > 128 || nstages < 8) return {1, nstages};
+  if (nstages < 8) return {1, nstages};
+  if (blocks > 128) {
+    if (blocks > 2048) return {1, nstages};
+    const int64_t whole = (blocks + CUS - 1) / CUS * nstages;
+    int64_t best = whole;
+    SplitPlan plan{1, nstages};
+    for (int want = 2; want <= 8 && want <= nstages / 4; want *= 2) {
+      const int sps = (nstages + want - 1) / want;
+      const int ks = (nstages + sps - 1) / sps;
+      const int64_t cost = (blocks * ks + CUS - 1) / CUS * sps;
+      if (cost * 10 <= whole * 9 && cost < best) {
+        best = cost;
+        plan = {ks, sps};
+      }
+    }
+    return plan;
+  }
   int ks = (int)(256 / blocks);
   if (ks > nstages / 4) ks = nstages / 4;
   if (ks > 64) ks = 64;
