@@ -59,20 +59,20 @@ def host_cpu() -> dict:
     return {"model": model, "logical_cpus": logical or (os.cpu_count() or 1), "physical_cores": len(cores) or None}
 
 
-def cpu_baseline(rows: int = 16384, reps: int = 10) -> dict:
+def cpu_baseline(z: torch.Tensor, E: torch.Tensor, reps: int = 10):
     """The reference's dense formulation (oracle/dense_port.py) on the host cores.
-    Sample: `rows` latent vectors per step (the N x K fp32 matrices must fit host memory), `reps` timed
-    steps after one warm-up.  The cost of the formulation is linear in the number of rows (three
-    N x K x D products and N x K elementwise passes), so vectors/s at the sample size is the rate
-    the full 4 Mi-row batch would run at, chunk after chunk."""
+    Sample: the first rows of the benchmark batch (`z`, a host copy: the N x K fp32 matrices must fit host
+    memory) against the benchmark's initial codebook `E`, `reps` timed steps after one warm-up.  The cost of
+    the formulation is linear in the number of rows (three N x K x D products and N x K elementwise
+    passes), so vectors/s at the sample size is the rate the full 4 Mi-row batch would run at, chunk after
+    chunk.  Returns (the baseline entry, the indices the warm-up step chose from the fresh state): the
+    latter feed the near-tie census of the parity gate."""
     from oracle.dense_port import dense_forward, new_state
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
     torch.set_num_threads(threads)
-    g = torch.Generator().manual_seed(0)
-    z = torch.randn(rows // (H * W), D, H, W, generator=g)
-    E = torch.randn(K, D, generator=torch.Generator().manual_seed(1))
+    rows = z.shape[0] * H * W
     st = new_state(E)
-    dense_forward(z, st, BETA, DECAY, EPS, 1.0, True)  # warm-up
+    dense_idx = dense_forward(z, st, BETA, DECAY, EPS, 1.0, True)[3].reshape(-1).clone()  # warm-up
     times = []
     for _ in range(reps):
         t0 = time.perf_counter()
@@ -88,17 +88,20 @@ def cpu_baseline(rows: int = 16384, reps: int = 10) -> dict:
                       f"{rows} vectors/step, {reps} steps after 1 warm-up, value = rows / median step time "
                       f"({med:.3f} s; min {best:.3f} s), {threads} torch threads, torch {torch.__version__} CPU; "
                       f"cost is linear in the rows, so the rate holds for the 4 Mi-row batch processed in chunks "
-                      f"of this size ({4 * 1024 * 1024 / rows * med:.0f} s extrapolated)"}
+                      f"of this size ({4 * 1024 * 1024 / rows * med:.0f} s extrapolated)"}, dense_idx
 
 
-def parity_gate(z: torch.Tensor, E0: torch.Tensor, rows: int = 16384) -> dict:
+def parity_gate(zs: torch.Tensor, E0: torch.Tensor, dense_idx=None) -> dict:
     """Correctness gate printed beside the throughput: one training step from a fresh EMA state
-    on the first `rows` latent vectors of the benchmark batch, on the GPU and through the
-    index-based C restatement (oracle/vq_oracle.c) on the host cores, which is timed as well."""
+    on the first latent vectors of the benchmark batch (`zs`), on the GPU and through the
+    index-based C restatement (oracle/vq_oracle.c) on the host cores, which is timed as well.
+    `dense_idx`: the indices the dense one-hot formulation (the reference's own arithmetic: sgemm +
+    torch.argmin) chose for the same rows on the host; every row where the GPU disagrees with them is
+    classified in float64 as a near-tie or not (tools/near_tie_census.py)."""
     from oracle import vq_oracle as vo
+    from tools.near_tie_census import census
     from vq_vae_amd import ops
-    dev = z.device
-    zs = z[: rows // (H * W)].contiguous()
+    dev = zs.device
     E = E0.clone()
     ema_w = torch.zeros(K, D, device=dev); cs = torch.zeros(K, device=dev); usage = torch.zeros(K, device=dev)
     out = ops.quantize_step(zs, E, ema_w, cs, usage, beta=BETA, decay=DECAY, epsilon=EPS, temperature=1.0,
@@ -115,7 +118,12 @@ def parity_gate(z: torch.Tensor, E0: torch.Tensor, rows: int = 16384) -> dict:
 
     idx = out.indices.reshape(-1).cpu().numpy()
     counts = (out.counts.cpu().numpy().astype(np.int64) & 0xFFFFFFFF)
-    return {"rows": int(idx.size), "index_mismatches": int((idx != ref["indices"].reshape(-1)).sum()),
+    vs_dense = None
+    if dense_idx is not None:
+        vs_dense = census(zs.cpu(), E0.cpu(), out.indices.cpu(), dense_idx)
+        vs_dense["against"] = "dense one-hot torch formulation on the host (MKL sgemm + torch.argmin), same rows"
+    return {"rows": int(idx.size), "vs_dense_formulation": vs_dense,
+            "index_mismatches": int((idx != ref["indices"].reshape(-1)).sum()),
             "histogram_equal": bool(np.array_equal(counts, np.asarray(ref["counts"]).astype(np.int64))),
             "max_rel_err": {"quantized": rel(out.quantized.cpu().numpy(), ref["quantized"]),
                             "loss": rel(out.loss.item(), ref["loss"]),
@@ -371,9 +379,17 @@ def main() -> None:
         if small is not None:
             line["per_gpu_training_batch"] = small
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            zs = z[: max(1, min(16384, rows) // (H * W))].contiguous()
+            line["cpu_baseline"], dense_idx = cpu_baseline(zs.cpu(), E0.cpu())
             try:
-                line["parity"] = parity_gate(z, E0)
+                line["parity"] = parity_gate(zs, E0, dense_idx)
+                # the same census over the whole batch against the formulation's GPU form (rocBLAS sgemm +
+                # torch.argmin, 64 Ki rows at a time), outside every timed region
+                from tools.near_tie_census import census, dense_indices
+                got = ops.search(z, E0, ws, want_quantized=False)["indices"]
+                full = census(z, E0, got, dense_indices(z, E0))
+                full["against"] = "dense torch formulation on the GPU (rocBLAS sgemm + torch.argmin), whole batch"
+                line["parity"]["vs_dense_formulation_gpu"] = full
             except Exception as exc:
                 line["parity"] = {"error": f"{type(exc).__name__}: {exc}"}
         print(json.dumps(line), flush=True)

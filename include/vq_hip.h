@@ -42,6 +42,20 @@ enum {
 int vq_version(void);
 const char* vq_status_string(int status);
 
+/*
+ * Optional one-time set-up of a device, for callers that record the entry points into a HIP graph
+ * or must keep the first timed call free of set-up work.  No counterpart in the reference.  For GPU
+ * `device` it raises the dynamic-LDS limit of every kernel of the library that needs more than the
+ * 64 KiB default (hipFuncSetAttribute) and looks up the device address of the library's static
+ * scratch array (vq_pairwise_stats_static).  Without this call each entry point does the same for
+ * its own kernels the first time it runs on a device -- host-side work that must not fall inside a
+ * stream capture.  The call makes `device` current while it runs and restores the caller's current
+ * device; it allocates nothing and may be repeated.
+ */
+int vq_init(int device);
+/* Number of kernels vq_init prepares (entered in the library's table when it is loaded); diagnostic. */
+int vq_large_lds_kernels(void);
+
 /* ---- sizes of the caller-owned work buffers (bytes; every buffer 256-byte aligned) ---- */
 size_t vq_image_bytes(int K, int D);            /* codebook image, the search's MFMA A operand     */
 size_t vq_norms_bytes(int K);                   /* squared norms of the (padded) codebook          */
@@ -160,6 +174,9 @@ int vq_code_histogram(const void* idx, int idx_is_64, int64_t M, int K, uint32_t
  * finer.  A batch holding NaN/inf takes a float-atomic path that propagates them like the
  * reference.  Rows whose index falls outside [code_base, code_base + K) are skipped
  * (codebook-row sharding: a rank accumulates only the rows its shard won).
+ * Limits: N < 2^31 rows per call and code_base + K < 2^31 (row numbers and codes are 32-bit inside
+ * the kernels; N is an int64_t only for uniformity of the ABI): VQ_ERR_UNSUPPORTED beyond them, as
+ * for vq_search.  A batch of 2^31 rows or more is passed as several calls whose slabs the caller adds.
  */
 int vq_ema_scatter(const float* z, int layout, int64_t N, int D, int64_t HW, const int32_t* idx32, int K,
                    int64_t code_base, int zmax_valid, int32_t* control, float* slabs, int nslab, void* stream);
@@ -340,6 +357,10 @@ int vq_pairwise_rows(const float* E, const float* image, const float* e2, int K,
  * call allocates and frees nothing.  K is limited to VQ_PAIRWISE_STATIC_MAX_K (VQ_ERR_TOO_LARGE
  * beyond it).  All calls on one GPU share that array: calls that overlap on one GPU (two streams,
  * two threads) race; calls in stream order do not, and nothing has to be cleared between them.
+ * The array used is that of the GPU `stream` belongs to (for the NULL stream: the current device),
+ * which must also be where E, image, ... live.  The first call on a GPU looks the array's address up
+ * (hipGetSymbolAddress, host-side work that may load the code object): under stream capture call
+ * vq_init(device) beforehand, so that no call inside the capture is a first call.
  */
 #define VQ_PAIRWISE_STATIC_MAX_K 65536
 int vq_pairwise_stats_static(const float* E, const float* image, const float* e2, int K, int D, float* nn_dist,

@@ -316,3 +316,31 @@ def test_reference_layout_checkpoint_file_loads(tmp_path):
     assert again["epoch"] == 8 and again["model_config"] == ck["model_config"]
     for k in ck["quantizer_state"]:
         assert torch.equal(again["quantizer_state"][k], ck["quantizer_state"][k])
+
+
+def test_light_checkpoint_holds_what_the_trainer_loader_reads(tmp_path):
+    """The same key accesses as the reference trainer's loader (vqvae/vqgan_trainer.py:474-526 with
+    skip_optimizer): model_config['vq_num_embed'], 'vqgan_state_dict', 'discriminator_state_dict' (indexed,
+    not .get), the optional scheduler states, 'codebook_stats', 'epoch', 'best_val_loss' -- and none of the
+    optimizer / scaler entries the light variant drops (:442)."""
+    import torch
+    from vq_vae_amd import EMAVectorQuantizer, checkpoint
+    m = EMAVectorQuantizer(32, 16, 3.0)
+    model_state = {"quantize." + k: v for k, v in m.state_dict().items()}
+    disc = {"model.0.weight": torch.randn(4, 3, 4, 4), "model.0.bias": torch.zeros(4)}
+    sched = {"last_epoch": 5, "_step_count": 6, "base_lrs": [1e-4]}
+    path = tmp_path / "vqgan_best_light.pt"
+    torch.save(checkpoint.light_checkpoint(model_state, epoch=5, best_val_loss=0.7, codebook_stats=[{"epoch": 5}],
+                                           discriminator_state=disc, g_scheduler_state=sched, d_scheduler_state=sched),
+               str(path))
+    ck = torch.load(str(path), map_location="cpu", weights_only=True)
+    assert ck["model_config"]["vq_num_embed"] == 32 and ck["model_config"]["vq_embed_dim"] == 16   # :478-487
+    m2 = EMAVectorQuantizer(32, 16, 3.0)
+    m2.load_state_dict({k[len("quantize."):]: v for k, v in ck["vqgan_state_dict"].items()}, strict=True)   # :491
+    assert set(ck["discriminator_state_dict"]) == set(disc)                                        # :492
+    assert ck["g_scheduler_state_dict"]["last_epoch"] == 5 and "d_scheduler_state_dict" in ck       # :501-504
+    assert ck["codebook_stats"] == [{"epoch": 5}] and ck.get("epoch", 0) + 1 == 6                   # :517-521
+    assert ck.get("best_val_loss", 0.0) == 0.7                                                      # :523
+    assert not [k for k in ck if "optimizer" in k or "scaler" in k]                                 # :442
+    # without a discriminator state the file serves the utilisation checker only: the key is absent
+    assert "discriminator_state_dict" not in checkpoint.light_checkpoint(model_state, epoch=1)

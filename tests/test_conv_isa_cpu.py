@@ -1,4 +1,4 @@
-"""Static check of vq_conv1x1_full_kernel's counted stage wait (no GPU needed; hipcc cross-compiles).
+"""Static check of the counted stage wait of vq_conv1x1_kernel<D, NCHW, FULL = true> (no GPU needed; hipcc cross-compiles).
 
 The kernel lets a stage's barrier wait for the LDS-DMA of the next stage only, not for the stores
 issued after it: `s_waitcnt vmcnt(n)` with n = the number of store instructions a wave issues behind
@@ -29,7 +29,7 @@ def assembly(tmp_path_factory):
 
 
 def test_counted_waits_match_the_stores_behind_the_dma(assembly):
-    kernels = re.findall(r"^(_ZN\S*vq_conv1x1_full_kernel\S*):\s*(?:;.*)?$", assembly, re.M)
+    kernels = re.findall(r"^(_ZN\S*vq_conv1x1_kernelILi\d+ELb[01]ELb1EE\S*):\s*(?:;.*)?$", assembly, re.M)
     assert len(kernels) == 10, kernels          # 5 channel counts x 2 layouts
     for name in kernels:
         start = assembly.index(name + ":")

@@ -65,3 +65,33 @@ def test_static_pairwise_rejects_sizes_beyond_its_maximum():
                                       ops._ptr(t), ops._ptr(t), ops._stream(dev))
     assert rc == 3
     assert b"maximum" in lib.vq_status_string(rc)
+
+
+def test_static_pairwise_allocates_and_frees_nothing():
+    """The property the entry point exists for: after the first call on the device (which looks the
+    scratch array's address up), a call changes neither the device's free memory (hipMemGetInfo, which
+    sees every allocation of the process, the library's included) nor torch's allocator."""
+    lib = load()
+    dev = torch.device("cuda:0")
+    assert lib.vq_init(0) == 0 and lib.vq_large_lds_kernels() > 0      # set-up outside the measured call
+    K, D = 2048, 64
+    E = torch.from_numpy(gauss(903, (K, D))).to(dev)
+    ws = ops.Workspace(dev)
+    image, e2, control = ops.prepare_codebook(E, ws)
+    nn_dist = torch.empty(K, dtype=torch.float32, device=dev)
+    nn_idx = torch.empty(K, dtype=torch.int64, device=dev)
+    out = torch.empty(3, dtype=torch.float64, device=dev)
+    s = ops._stream(dev)
+    args = (ops._ptr(E), ops._ptr(image), ops._ptr(e2), K, D, ops._ptr(nn_dist), ops._ptr(nn_idx), ops._ptr(out),
+            ops._ptr(control), s)
+    assert lib.vq_pairwise_stats_static(*args) == 0                    # first call on this device
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(dev)
+    alloc0, reserved0 = torch.cuda.memory_allocated(dev), torch.cuda.memory_reserved(dev)
+    for _ in range(3):
+        assert lib.vq_pairwise_stats_static(*args) == 0
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(dev)
+    assert free1 == free0, (free0, free1)
+    assert torch.cuda.memory_allocated(dev) == alloc0 and torch.cuda.memory_reserved(dev) == reserved0
+    assert np.isfinite(out.cpu().numpy()).all()

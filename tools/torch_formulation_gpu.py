@@ -9,6 +9,10 @@ fit comfortably, and prints latent vectors per second next to this library's ste
 inputs.  It is a yardstick, not part of the product or of the tests.
 
     python tools/torch_formulation_gpu.py [rows ...]        (default: 65536 262144 1048576)
+
+For every size it also prints the near-tie census: the rows on which this library's indices differ
+from the dense formulation's (rocBLAS accumulates z.e in its own order), each classified in float64 as
+a near-tie or not (tools/near_tie_census.py), for T = 1 and T = 2.5.
 """
 import os
 import sys
@@ -76,6 +80,13 @@ def main():
             out[mode] = timed(lambda: ops.quantize_step(z, E, w, c, u, beta=3.0, decay=0.95, epsilon=1e-5,
                                                         temperature=1.0, training=True, ws=ws,
                                                         filtered=mode == "filtered"), 5)
+        import json
+        from tools.near_tie_census import census, dense_indices
+        for T in (1.0, 2.5):
+            got = ops.search(z, E0, ws, temperature=T, want_quantized=False)["indices"]
+            c = census(z, E0, got, dense_indices(z, E0, T), T)
+            c.update({"K": K, "D": D, "temperature": T})
+            print("census " + json.dumps(c), flush=True)
         print(f"N={N}: dense torch formulation {t_ref * 1e3:.1f} ms = {N / t_ref / 1e6:.2f} M vec/s "
               f"(peak {peak:.0f} GiB) | this library fp32 {out['fp32'] * 1e3:.2f} ms = {N / out['fp32'] / 1e6:.1f} M vec/s, "
               f"filtered {out['filtered'] * 1e3:.2f} ms = {N / out['filtered'] / 1e6:.1f} M vec/s", flush=True)

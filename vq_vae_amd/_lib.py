@@ -19,6 +19,8 @@ LAYOUT_ND, LAYOUT_NCHW = 0, 1
 SIGNATURES = {
     "vq_version": (c_int, []),
     "vq_status_string": (ctypes.c_char_p, [c_int]),
+    "vq_init": (c_int, [c_int]),
+    "vq_large_lds_kernels": (c_int, []),
     "vq_image_bytes": (c_size_t, [c_int, c_int]),
     "vq_norms_bytes": (c_size_t, [c_int]),
     "vq_search_blocks": (c_int64, [c_int64]),

@@ -83,12 +83,26 @@ def load_reference_checkpoint(path: str, map_location="cpu") -> dict:
 
 
 def light_checkpoint(model_state: Dict[str, torch.Tensor], epoch: int, best_val_loss: float = 0.0,
-                     codebook_stats=None, extra: dict = None) -> dict:
-    """The dict of the reference's light checkpoint variant (vqvae/vqgan_trainer.py:409-423 without
-    the optimizer / scaler entries, :442): ``torch.save`` it and the reference's loaders
-    (vqvae/vqgan_trainer.py:474-526, vqvae/codebook_utilization_check.py:18-53) read it."""
+                     codebook_stats=None, extra: dict = None,
+                     discriminator_state: Dict[str, torch.Tensor] = None,
+                     g_scheduler_state: dict = None, d_scheduler_state: dict = None) -> dict:
+    """The dict of the reference's light checkpoint variant: the trainer's checkpoint
+    (vqvae/vqgan_trainer.py:409-423) without the entries whose key contains 'optimizer' or 'scaler'
+    (:442) -- so the discriminator's weights and the schedulers' states stay in it.
+
+    Readers: vqvae/codebook_utilization_check.py:18-53 needs only 'vqgan_state_dict'.  The trainer's
+    own loader (vqvae/vqgan_trainer.py:474-526) also indexes 'discriminator_state_dict' (:492) and gives
+    up without it, so pass ``discriminator_state`` for a file the trainer is to resume from
+    (with ``skip_optimizer``; the optimizer entries are what the light variant leaves out);
+    ``g_scheduler_state`` / ``d_scheduler_state`` are stored under the keys it looks for (:501-504)."""
     out = {"epoch": int(epoch), "vqgan_state_dict": {k: v.detach().cpu() for k, v in model_state.items()},
            "best_val_loss": float(best_val_loss), "codebook_stats": list(codebook_stats or []),
            "model_config": model_config(model_state)}
+    if discriminator_state is not None:
+        out["discriminator_state_dict"] = {k: v.detach().cpu() for k, v in discriminator_state.items()}
+    if g_scheduler_state is not None:
+        out["g_scheduler_state_dict"] = g_scheduler_state
+    if d_scheduler_state is not None:
+        out["d_scheduler_state_dict"] = d_scheduler_state
     out.update(extra or {})
     return out

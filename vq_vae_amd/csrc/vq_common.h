@@ -22,7 +22,7 @@ constexpr int VQ_FIX_WGS = 1024;
 __host__ __device__ inline int vq_kpad(int K) { return (K + VQ_STAGE_CODES - 1) / VQ_STAGE_CODES * VQ_STAGE_CODES; }
 // One stage of the codebook image: 64 codes x D floats in MFMA-fragment order, then the
 // 64 squared norms of the stage padded to one 1 KiB LDS-DMA piece.
-__host__ __device__ inline size_t vq_stage_floats(int D) { return (size_t)VQ_STAGE_CODES * D + 256; }
+__host__ __device__ constexpr size_t vq_stage_floats(int D) { return (size_t)VQ_STAGE_CODES * D + 256; }
 
 __host__ __device__ inline bool vq_fast_dim(int D) { return D == 16 || D == 32 || D == 64 || D == 128 || D == 256; }
 
@@ -36,6 +36,28 @@ static inline int vq_hip_status(hipError_t e) { return e == hipSuccess ? VQ_OK :
     hipError_t _e = (expr);                        \
     if (_e != hipSuccess) return vq_hip_status(_e); \
   } while (0)
+
+// ---- kernels whose dynamic LDS exceeds the 64 KiB default ----------------------------------
+// Such a kernel needs hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per device before its
+// first launch.  Every launcher goes through vq_lds_ready<kernel, bytes>(): the kernel is entered
+// in a process-wide table when the library is loaded (static registration), the attribute is set
+// on the first launch on a device -- or up front for all kernels by vq_init(device), which is what a
+// caller does before stream capture, where the first-launch path would run inside the capture.
+void vq_lds_register(const void* kern, int bytes);
+int vq_lds_ensure(const void* kern, int bytes, int* dev_out);
+struct VqLdsRegistrar {
+  VqLdsRegistrar(const void* k, int b) { vq_lds_register(k, b); }
+};
+template <auto Kern, int Bytes>
+struct VqLdsReg {
+  static inline VqLdsRegistrar r{reinterpret_cast<const void*>(Kern), Bytes};
+};
+// Returns a status; *dev_out (may be null) receives the current device ordinal.
+template <auto Kern, int Bytes>
+inline int vq_lds_ready(int* dev_out = nullptr) {
+  (void)&VqLdsReg<Kern, Bytes>::r;  // odr-use: instantiates the registration
+  return vq_lds_ensure(reinterpret_cast<const void*>(Kern), Bytes, dev_out);
+}
 
 // torch.argmin's replacement rule: NaN is below everything and the first NaN stays.
 __device__ __forceinline__ bool vq_argmin_takes(float d, float best) {

@@ -107,6 +107,9 @@ __global__ __launch_bounds__(512, 1) void vq_wgrad_kernel(WgradArgs a) {
     wgrad_stage_copy<NCHW>(a.gy, a.Co, o0, a.HW, a.N, s_begin, lds, wave, lane);
     wgrad_stage_copy<NCHW>(a.x, a.Ci, i0, a.HW, a.N, s_begin, lds + WG_OP_FLOATS, wave, lane);
   }
+  // The barriers that publish a stage must see this wave's LDS-DMA landed: vmcnt(0), spelled out
+  // rather than left to the fence the compiler happens to emit for __syncthreads().
+  __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
 
   int cur = 0;
@@ -188,6 +191,7 @@ __global__ __launch_bounds__(512, 1) void vq_wgrad_kernel(WgradArgs a) {
               acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ta][r], bv[tb][r], acc[ta][tb], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the DMA of stage st + 1 (see above)
     __syncthreads();
     cur ^= 1;
   }
@@ -290,16 +294,9 @@ int vq_conv1x1_wgrad(const float* gy, const float* x, int layout, int64_t N, int
   a.tiles_i = p.tiles_i;
   a.part = static_cast<float*>(work);
   hipStream_t s = (hipStream_t)stream;
-  const size_t lds_bytes = 2 * WG_STAGE_FLOATS * 4;
-  static bool attr_done[2][64] = {};
-  int dev = 0;
-  VQ_CHECK_HIP(hipGetDevice(&dev));
-  if (!attr_done[nchw][dev & 63]) {
-    const void* kern = nchw ? reinterpret_cast<const void*>(vq_wgrad_kernel<true>)
-                            : reinterpret_cast<const void*>(vq_wgrad_kernel<false>);
-    VQ_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    attr_done[nchw][dev & 63] = true;
-  }
+  constexpr int lds_bytes = 2 * WG_STAGE_FLOATS * 4;
+  const int arc = nchw ? vq_lds_ready<vq_wgrad_kernel<true>, lds_bytes>() : vq_lds_ready<vq_wgrad_kernel<false>, lds_bytes>();
+  if (arc != VQ_OK) return arc;
   const int tiles = p.tiles_o * p.tiles_i;
   const dim3 grid((unsigned)p.split, (unsigned)tiles), block(512);
   if (nchw) hipLaunchKernelGGL(vq_wgrad_kernel<true>, grid, block, lds_bytes, s, a);

@@ -639,16 +639,10 @@ int vq_ema_scatter(const float* z, int layout, int64_t N, int D, int64_t HW, con
   const bool vec4 = nchw && (HW % 4 == 0) && ((reinterpret_cast<uintptr_t>(z) & 15) == 0) &&
                     ((reinterpret_cast<uintptr_t>(idx32) & 15) == 0);
   const int mode = vec4 ? 2 : (nchw ? 1 : 0);
-  const void* kern = mode == 2 ? reinterpret_cast<const void*>(vq_scatter_kernel<2>)
-                   : mode == 1 ? reinterpret_cast<const void*>(vq_scatter_kernel<1>)
-                               : reinterpret_cast<const void*>(vq_scatter_kernel<0>);
-  static bool attr_done[3][64] = {};
-  int dev = 0;
-  VQ_CHECK_HIP(hipGetDevice(&dev));
-  if (!attr_done[mode][dev & 63]) {
-    VQ_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SCAT_KR * 8));
-    attr_done[mode][dev & 63] = true;
-  }
+  const int arc = mode == 2 ? vq_lds_ready<vq_scatter_kernel<2>, 2 * SCAT_KR * 8>()
+                : mode == 1 ? vq_lds_ready<vq_scatter_kernel<1>, 2 * SCAT_KR * 8>()
+                            : vq_lds_ready<vq_scatter_kernel<0>, 2 * SCAT_KR * 8>();
+  if (arc != VQ_OK) return arc;
   const FastDiv fd = make_fastdiv(nchw ? (uint32_t)HW : 1u);
   const dim3 grid((D + 1) / 2, p.nslab, kr);
   if (mode == 2)

@@ -648,16 +648,10 @@ __global__ __launch_bounds__(256) void vqf_verify_kernel(VerifyArgs a) {
 template <int D, bool NCHW, int R>
 int launch_filter(const FilterArgs& a, hipStream_t s) {
   constexpr int STAGE_B = FQ_STAGE_TILES * (D / 16 + 1) * 1024;
-  const size_t lds_bytes = 2 * STAGE_B + D * 4;
+  constexpr int lds_bytes = 2 * STAGE_B + D * 4;
   auto kern = vqf_filter_kernel<D, NCHW, R>;
-  static bool attr_done[64] = {};
-  int dev = 0;
-  VQ_CHECK_HIP(hipGetDevice(&dev));
-  if (!attr_done[dev & 63]) {
-    VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds_bytes));
-    attr_done[dev & 63] = true;
-  }
+  const int arc = vq_lds_ready<vqf_filter_kernel<D, NCHW, R>, lds_bytes>();
+  if (arc != VQ_OK) return arc;
   // first pass: every row, the split known here; second pass (list mode): at most N/8 rows reach it,
   // and the kernel derives its split from the counter, so the grid covers the largest one
   const int64_t rows = a.row_list ? (a.N + 7) / 8 : a.N;

@@ -316,16 +316,9 @@ int vq_ema_scatter_sorted(const float* z, int64_t N, int D, const int32_t* idx32
   }
   const SortPlan p = sort_plan(N);
   const SortWork w = carve(work, N, K, D);
-  static bool attr_done[64] = {};
-  int dev = 0;
-  VQ_CHECK_HIP(hipGetDevice(&dev));
-  if (!attr_done[dev & 63]) {
-    VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ss_hist_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, SS_MAX_K * 4));
-    VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ss_rank_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, SS_MAX_K * 4));
-    attr_done[dev & 63] = true;
-  }
+  int arc = vq_lds_ready<ss_hist_kernel, SS_MAX_K * 4>();
+  if (arc == VQ_OK) arc = vq_lds_ready<ss_rank_kernel, SS_MAX_K * 4>();
+  if (arc != VQ_OK) return arc;
   VQ_CHECK_HIP(hipMemsetAsync(w.acc, 0, (size_t)K * D * 8, s));
   hipLaunchKernelGGL(ss_hist_kernel, dim3(p.chunks), dim3(SS_THREADS), (size_t)K * 4, s, idx32, (int)N, K,
                      (int)code_base, p.chunk_rows, w.hist);

@@ -252,7 +252,8 @@ __global__ __launch_bounds__(512 / CT, 2 / CT) void vq_search_mfma_kernel(Search
 #pragma unroll
   for (int q = 0; q < 4; ++q) e2B[q] = f32x4{__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()};
 
-  __syncthreads();  // stage 0 has landed (the barrier waits for this wave's DMA first)
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's share of the stage-0 DMA (and its z loads)
+  __syncthreads();                     // stage 0 has landed
 
   int cur = 0;
   for (int st = 0; st < nst; ++st) {
@@ -320,7 +321,8 @@ __global__ __launch_bounds__(512 / CT, 2 / CT) void vq_search_mfma_kernel(Search
 #pragma unroll
     for (int q = 0; q < 4; ++q) e2B[q] = e2s[8 + 2 * q];
 
-    __syncthreads();  // every wave is done with buf; the DMA of stage st+1 has landed
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's share of the DMA of stage st+1
+    __syncthreads();                     // every wave is done with buf; stage st+1 has landed
     cur ^= 1;
   }
   {
@@ -506,7 +508,10 @@ __device__ __forceinline__ void conv_store_full(const f32x16& c, int code0, int 
   }
 }
 
-template <int D, bool NCHW>
+// FULL: every output channel of every tile exists (C_out a multiple of 64).  The stores are then
+// unconditional, a wave issues a fixed number of them behind each stage's DMA, and the stage barrier
+// waits with a counted s_waitcnt for the DMA alone instead of draining the stores too.
+template <int D, bool NCHW, bool FULL>
 __global__ __launch_bounds__(512, 2) void vq_conv1x1_kernel(ConvArgs a) {
   constexpr int NW = 8;
   constexpr int S = D / 2;
@@ -579,7 +584,10 @@ __global__ __launch_bounds__(512, 2) void vq_conv1x1_kernel(ConvArgs a) {
         af = an;
       }
     }
-    if (st > 0) conv_store_tile<NCHW>(cB, (st - 1) * VQ_STAGE_CODES + 32, h, a.Cout, valid, obase, cstride);
+    if (st > 0) {
+      if (FULL) conv_store_full<NCHW>(cB, (st - 1) * VQ_STAGE_CODES + 32, h, obase, cstride);
+      else conv_store_tile<NCHW>(cB, (st - 1) * VQ_STAGE_CODES + 32, h, a.Cout, valid, obase, cstride);
+    }
 
     // second half: output channels [64 st + 32, 64 st + 64) into set B; store set A
 #pragma unroll
@@ -598,118 +606,25 @@ __global__ __launch_bounds__(512, 2) void vq_conv1x1_kernel(ConvArgs a) {
         af = an;
       }
     }
-    conv_store_tile<NCHW>(cA, st * VQ_STAGE_CODES, h, a.Cout, valid, obase, cstride);
+    if (FULL) conv_store_full<NCHW>(cA, st * VQ_STAGE_CODES, h, obase, cstride);
+    else conv_store_tile<NCHW>(cA, st * VQ_STAGE_CODES, h, a.Cout, valid, obase, cstride);
 
-    __syncthreads();
+    if (FULL) {
+      // The barrier must see this wave's DMA of stage st+1 landed, not its stores: vector memory
+      // operations retire in issue order, and exactly SPT (first stage) or twice that many stores
+      // were issued after the DMA, so waiting for all but those is enough.  (Rows beyond N are clamped
+      // duplicates that rewrite the last row's values, so the count does not depend on `valid`.)
+      constexpr int SPT = NCHW ? 16 : 4;
+      if (st == 0) __builtin_amdgcn_s_waitcnt(((SPT & 15) | ((SPT >> 4) << 14)) | 0x0F70);
+      else __builtin_amdgcn_s_waitcnt((((2 * SPT) & 15) | (((2 * SPT) >> 4) << 14)) | 0x0F70);
+      __builtin_amdgcn_s_barrier();
+    } else {
+      __syncthreads();
+    }
     cur ^= 1;
   }
-  conv_store_tile<NCHW>(cB, (a.nstages - 1) * VQ_STAGE_CODES + 32, h, a.Cout, valid, obase, cstride);
-}
-
-template <int D, bool NCHW>
-__global__ __launch_bounds__(512, 2) void vq_conv1x1_full_kernel(ConvArgs a) {
-  constexpr int NW = 8;
-  constexpr int S = D / 2;
-  constexpr int G = D / 8;
-  constexpr int STAGE_F = VQ_STAGE_CODES * D + 256;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int j = lane & 31, h = lane >> 5;
-  const int64_t row0 = (int64_t)blockIdx.x * VQ_WG_ROWS + wave * 32;
-
-  stage_copy<D, NW>(a.image, 0, lds, wave, lane);
-
-  // x tile into registers in B-operand order: xr[s] = x[row][2s + h]
-  float xr[S];
-  int64_t n = row0 + j;
-  const bool valid = n < a.N;
-  if (!valid) n = a.N - 1;
-  float* obase;
-  int64_t cstride;
-  if (NCHW) {
-    const int64_t b = n / a.HW, hw = n - b * a.HW;
-    const float* src = a.x + (b * D + h) * a.HW + hw;
-    const int64_t xstride = 2 * a.HW;
-#pragma unroll
-    for (int s = 0; s < S; ++s) xr[s] = src[(int64_t)s * xstride];
-    obase = a.out + b * a.Cout * a.HW + hw;
-    cstride = a.HW;
-  } else {
-    // (dword loads: a 16-byte load would hold four registers to leave two, and the tile fills the file)
-    const float* src = a.x + n * D + h;
-#pragma unroll
-    for (int m = 0; m < D / 4; ++m) {
-      xr[2 * m] = src[4 * m];
-      xr[2 * m + 1] = src[4 * m + 2];
-    }
-    obase = a.out + n * a.Cout;
-    cstride = 1;
-  }
-
-  f32x16 cA, cB;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) cB[i] = 0.0f;
-
-  __syncthreads();
-
-  int cur = 0;
-  for (int st = 0; st < a.nstages; ++st) {
-    float* buf = lds + cur * STAGE_F;
-    if (st + 1 < a.nstages) stage_copy<D, NW>(a.image, st + 1, lds + (cur ^ 1) * STAGE_F, wave, lane);
-    const f32x4* A = reinterpret_cast<const f32x4*>(buf) + lane;
-    const f32x4* bs = reinterpret_cast<const f32x4*>(buf + VQ_STAGE_CODES * D) + h;
-
-    // first half: output channels [64 st, 64 st + 32) into set A, starting from their bias;
-    // store set B of stage st-1
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 b4 = bs[2 * q];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) cA[4 * q + r] = b4[r];
-    }
-    {
-      f32x4 af = A[0];
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const f32x4 an = A[(g + 1 < G ? g + 1 : g) * 64];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) cA = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], xr[4 * g + q], cA, 0, 0, 0);
-        af = an;
-      }
-    }
-    if (st > 0) conv_store_full<NCHW>(cB, (st - 1) * VQ_STAGE_CODES + 32, h, obase, cstride);
-
-    // second half: output channels [64 st + 32, 64 st + 64) into set B; store set A
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 b4 = bs[8 + 2 * q];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) cB[4 * q + r] = b4[r];
-    }
-    {
-      f32x4 af = A[G * 64];
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const f32x4 an = A[(G + (g + 1 < G ? g + 1 : g)) * 64];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) cB = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], xr[4 * g + q], cB, 0, 0, 0);
-        af = an;
-      }
-    }
-    conv_store_full<NCHW>(cA, st * VQ_STAGE_CODES, h, obase, cstride);
-
-    // The barrier must see this wave's DMA of stage st+1 landed, not its stores: vector memory
-    // operations retire in issue order, and exactly STORES_PER_TILE (first stage) or twice that many
-    // stores were issued after the DMA, so waiting for all but those is enough.
-    constexpr int SPT = NCHW ? 16 : 4;
-    if (st == 0) __builtin_amdgcn_s_waitcnt(((SPT & 15) | ((SPT >> 4) << 14)) | 0x0F70);
-    else __builtin_amdgcn_s_waitcnt((((2 * SPT) & 15) | (((2 * SPT) >> 4) << 14)) | 0x0F70);
-    __builtin_amdgcn_s_barrier();
-    cur ^= 1;
-  }
-  conv_store_full<NCHW>(cB, (a.nstages - 1) * VQ_STAGE_CODES + 32, h, obase, cstride);
+  if (FULL) conv_store_full<NCHW>(cB, (a.nstages - 1) * VQ_STAGE_CODES + 32, h, obase, cstride);
+  else conv_store_tile<NCHW>(cB, (a.nstages - 1) * VQ_STAGE_CODES + 32, h, a.Cout, valid, obase, cstride);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -874,17 +789,12 @@ __global__ __launch_bounds__(512, 1) void vq_conv1x1_ws_kernel(ConvArgs a, int64
 
 template <int D>
 int launch_conv_ws(const ConvArgs& a, bool nchw, hipStream_t s) {
-  const size_t lds_bytes = (size_t)4 * 32 * D * 4 + 1024;
-  const void* kern = nchw ? reinterpret_cast<const void*>(vq_conv1x1_ws_kernel<D, true>)
-                          : reinterpret_cast<const void*>(vq_conv1x1_ws_kernel<D, false>);
-  static bool attr_done[2][64] = {};
+  constexpr int lds_bytes = 4 * 32 * D * 4 + 1024;
   static int cus[64] = {};
   int dev = 0;
-  VQ_CHECK_HIP(hipGetDevice(&dev));
-  if (!attr_done[nchw][dev & 63]) {
-    VQ_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    attr_done[nchw][dev & 63] = true;
-  }
+  const int rc = nchw ? vq_lds_ready<vq_conv1x1_ws_kernel<D, true>, lds_bytes>(&dev)
+                      : vq_lds_ready<vq_conv1x1_ws_kernel<D, false>, lds_bytes>(&dev);
+  if (rc != VQ_OK) return rc;
   if (!cus[dev & 63]) VQ_CHECK_HIP(hipDeviceGetAttribute(&cus[dev & 63], hipDeviceAttributeMultiprocessorCount, dev));
   const int64_t ntiles = (a.N + 31) / 32;
   const int gy = a.Cout / 256;
@@ -897,33 +807,29 @@ int launch_conv_ws(const ConvArgs& a, bool nchw, hipStream_t s) {
   return vq_hip_status(hipGetLastError());
 }
 
+template <bool NCHW, bool FULL> struct ConvTag { static constexpr bool nchw = NCHW, full = FULL; };
+
 template <int D>
 int launch_conv(const ConvArgs& a, bool nchw, hipStream_t s) {
   // whole 256-channel blocks of outputs, whole 32-row tiles per image, enough tiles for the ring to pay
   if constexpr (D >= 64) {
     if (a.Cout % 256 == 0 && (!nchw || a.HW % 32 == 0) && a.N >= 32 * 1024) return launch_conv_ws<D>(a, nchw, s);
   }
-  const size_t lds_bytes = 2 * vq_stage_floats(D) * 4 + 256;
-  // every output channel of every tile exists: the kernel whose stage barrier waits for the DMA only
+  constexpr int lds_bytes = (int)(2 * vq_stage_floats(D) * 4 + 256);
   const bool full = a.Cout % VQ_STAGE_CODES == 0;
-  const void* kern = full ? (nchw ? reinterpret_cast<const void*>(vq_conv1x1_full_kernel<D, true>)
-                                  : reinterpret_cast<const void*>(vq_conv1x1_full_kernel<D, false>))
-                          : (nchw ? reinterpret_cast<const void*>(vq_conv1x1_kernel<D, true>)
-                                  : reinterpret_cast<const void*>(vq_conv1x1_kernel<D, false>));
-  static bool attr_done[2][2][64] = {};
-  int dev = 0;
-  VQ_CHECK_HIP(hipGetDevice(&dev));
-  if (!attr_done[full][nchw][dev & 63]) {
-    VQ_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    attr_done[full][nchw][dev & 63] = true;
-  }
   const int64_t blocks = (a.N + VQ_WG_ROWS - 1) / VQ_WG_ROWS;
   const dim3 grid((unsigned)blocks), block(512);
-  if (full && nchw) hipLaunchKernelGGL((vq_conv1x1_full_kernel<D, true>), grid, block, lds_bytes, s, a);
-  else if (full) hipLaunchKernelGGL((vq_conv1x1_full_kernel<D, false>), grid, block, lds_bytes, s, a);
-  else if (nchw) hipLaunchKernelGGL((vq_conv1x1_kernel<D, true>), grid, block, lds_bytes, s, a);
-  else hipLaunchKernelGGL((vq_conv1x1_kernel<D, false>), grid, block, lds_bytes, s, a);
-  return vq_hip_status(hipGetLastError());
+  auto go = [&](auto kern_tag) {
+    constexpr bool N_ = decltype(kern_tag)::nchw, F_ = decltype(kern_tag)::full;
+    const int arc = vq_lds_ready<vq_conv1x1_kernel<D, N_, F_>, lds_bytes>();
+    if (arc != VQ_OK) return arc;
+    hipLaunchKernelGGL((vq_conv1x1_kernel<D, N_, F_>), grid, block, lds_bytes, s, a);
+    return vq_hip_status(hipGetLastError());
+  };
+  if (full && nchw) return go(ConvTag<true, true>{});
+  if (full) return go(ConvTag<false, true>{});
+  if (nchw) return go(ConvTag<true, false>{});
+  return go(ConvTag<false, false>{});
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1318,16 +1224,10 @@ __global__ __launch_bounds__(256) void vq_gather_st_kernel(const float* __restri
 
 template <int D, int CT, bool NCHW, bool TEMP, bool PAIRWISE>
 int launch_mfma(const SearchArgs& a, hipStream_t s) {
-  const size_t lds_bytes = 2 * vq_stage_floats(D) * 4 + 256;
+  constexpr int lds_bytes = (int)(2 * vq_stage_floats(D) * 4 + 256);
   auto kern = vq_search_mfma_kernel<D, CT, NCHW, TEMP, PAIRWISE>;
-  static bool attr_done[64] = {};  // per instantiation and device
-  int dev = 0;
-  VQ_CHECK_HIP(hipGetDevice(&dev));
-  if (!attr_done[dev & 63]) {
-    VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds_bytes));
-    attr_done[dev & 63] = true;
-  }
+  const int arc = vq_lds_ready<vq_search_mfma_kernel<D, CT, NCHW, TEMP, PAIRWISE>, lds_bytes>();
+  if (arc != VQ_OK) return arc;
   const int64_t blocks = (a.N + VQ_WG_ROWS - 1) / VQ_WG_ROWS;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)(a.ksplit > 1 ? a.ksplit : 1)), dim3(512 / CT), lds_bytes, s, a);
   return vq_hip_status(hipGetLastError());
@@ -1361,14 +1261,8 @@ int run_mfma(const SearchArgs& a, int D, bool nchw, bool temp, bool pairwise, hi
 
 int run_exact(const SearchArgs& a, int D, bool nchw, bool use_list, float* loss_out, int blocks, hipStream_t s) {
   const size_t lds_bytes = ((size_t)XR * D + XR + 2 * XR * 256) * 4;
-  static bool attr_done[64] = {};
-  int dev = 0;
-  VQ_CHECK_HIP(hipGetDevice(&dev));
-  if (!attr_done[dev & 63]) {
-    VQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vq_search_exact_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)XR * 4096 + XR + 2 * XR * 256) * 4)));
-    attr_done[dev & 63] = true;
-  }
+  const int arc = vq_lds_ready<vq_search_exact_kernel, (XR * 4096 + XR + 2 * XR * 256) * 4>();  // sized for D = 4096
+  if (arc != VQ_OK) return arc;
   hipLaunchKernelGGL(vq_search_exact_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, s, a, D, nchw ? 1 : 0,
                      use_list ? 1 : 0, loss_out);
   return vq_hip_status(hipGetLastError());

@@ -248,19 +248,47 @@ int vq_pairwise_rows(const float* E, const float* image, const float* e2, int K,
 static __device__ __align__(256) unsigned char vq_pw_scratch[VQ_PW_STATIC_SUM_BYTES + VQ_PW_STATIC_MM_BYTES];
 static void* vq_pw_scratch_ptr[64] = {};  // device address of vq_pw_scratch, per device ordinal
 
-int vq_pairwise_stats_static(const float* E, const float* image, const float* e2, int K, int D, float* nn_dist,
-                             int64_t* nn_idx, double* out, int32_t* control, void* stream) {
-  if (!E || !image || !e2 || !nn_dist || !nn_idx || !out || !control || K <= 0) return VQ_ERR_INVALID_ARG;
-  if (K > VQ_PAIRWISE_STATIC_MAX_K) return VQ_ERR_TOO_LARGE;
-  if (!vq_fast_dim(D)) return VQ_ERR_UNSUPPORTED;
-  int dev = 0;
-  VQ_CHECK_HIP(hipGetDevice(&dev));
+// Address of this device's copy of the array; `dev` must be the current device.
+static int pw_scratch_lookup(int dev) {
   if (dev < 0 || dev >= 64) return VQ_ERR_UNSUPPORTED;
   if (vq_pw_scratch_ptr[dev] == nullptr) {
     void* p = nullptr;
     VQ_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(vq_pw_scratch)));
     if (p == nullptr) return VQ_ERR_HIP_BASE + (int)hipErrorInvalidSymbol;
     vq_pw_scratch_ptr[dev] = p;
+  }
+  return VQ_OK;
+}
+
+// Device a stream belongs to (the current device for the NULL stream).
+static int stream_device(hipStream_t s, int* dev) {
+  int cur = 0;
+  VQ_CHECK_HIP(hipGetDevice(&cur));
+  *dev = cur;
+  if (s != nullptr) {
+    hipDevice_t d;
+    if (hipStreamGetDevice(s, &d) == hipSuccess) *dev = (int)d;
+    else (void)hipGetLastError();  // e.g. a special stream handle: keep the current device
+  }
+  return VQ_OK;
+}
+
+int vq_pairwise_stats_static(const float* E, const float* image, const float* e2, int K, int D, float* nn_dist,
+                             int64_t* nn_idx, double* out, int32_t* control, void* stream) {
+  if (!E || !image || !e2 || !nn_dist || !nn_idx || !out || !control || K <= 0) return VQ_ERR_INVALID_ARG;
+  if (K > VQ_PAIRWISE_STATIC_MAX_K) return VQ_ERR_TOO_LARGE;
+  if (!vq_fast_dim(D)) return VQ_ERR_UNSUPPORTED;
+  // the array of the GPU the stream (and so the kernels) run on, not of whatever device is current
+  int dev = 0, cur = 0;
+  int rc = stream_device((hipStream_t)stream, &dev);
+  if (rc != VQ_OK) return rc;
+  if (dev < 0 || dev >= 64) return VQ_ERR_UNSUPPORTED;
+  if (vq_pw_scratch_ptr[dev] == nullptr) {
+    VQ_CHECK_HIP(hipGetDevice(&cur));
+    if (cur != dev) VQ_CHECK_HIP(hipSetDevice(dev));
+    rc = pw_scratch_lookup(dev);
+    if (cur != dev) (void)hipSetDevice(cur);
+    if (rc != VQ_OK) return rc;
   }
   // Nothing in the array has to start at zero: every workgroup of the sweep overwrites its own
   // partials, the finish kernel reads exactly those, and the row list is indexed by a counter in
@@ -293,7 +321,19 @@ int vq_unpack_dist_index(const int64_t* packed, int64_t N, float* dmin, int64_t*
   return vq_hip_status(hipGetLastError());
 }
 
-int vq_version(void) { return 120; }
+int vq_version(void) { return 130; }
+
+int vq_init(int device) {
+  int count = 0, cur = 0;
+  VQ_CHECK_HIP(hipGetDeviceCount(&count));
+  if (device < 0 || device >= count || device >= 64) return VQ_ERR_INVALID_ARG;
+  VQ_CHECK_HIP(hipGetDevice(&cur));
+  if (cur != device) VQ_CHECK_HIP(hipSetDevice(device));
+  int rc = vq_lds_ensure(nullptr, 0, nullptr);   // every registered kernel, on the now-current device
+  if (rc == VQ_OK) rc = pw_scratch_lookup(device);
+  if (cur != device) (void)hipSetDevice(cur);
+  return rc;
+}
 
 const char* vq_status_string(int status) {
   if (status == VQ_OK) return "ok";
@@ -305,3 +345,57 @@ const char* vq_status_string(int status) {
 }
 
 }  // extern "C"
+
+// ---- table of the kernels that need more dynamic LDS than the default (see vq_common.h) ----------
+// Zero-initialised storage, so registration from other files' static initialisers works whatever
+// the order in which the files are initialised.
+namespace {
+struct LdsEntry { const void* kern; int bytes; bool done[64]; };
+constexpr int VQ_LDS_MAX = 512;
+LdsEntry g_lds[VQ_LDS_MAX];
+int g_lds_n = 0;
+
+LdsEntry* lds_find(const void* kern) {
+  for (int i = 0; i < g_lds_n; ++i)
+    if (g_lds[i].kern == kern) return &g_lds[i];
+  return nullptr;
+}
+}  // namespace
+
+void vq_lds_register(const void* kern, int bytes) {
+  LdsEntry* e = lds_find(kern);
+  if (e == nullptr && g_lds_n < VQ_LDS_MAX) {
+    e = &g_lds[g_lds_n++];
+    e->kern = kern;
+  }
+  if (e != nullptr && bytes > e->bytes) e->bytes = bytes;
+}
+
+extern "C" int vq_large_lds_kernels(void) { return g_lds_n; }
+
+// kern == nullptr: every registered kernel (vq_init).
+int vq_lds_ensure(const void* kern, int bytes, int* dev_out) {
+  int dev = 0;
+  VQ_CHECK_HIP(hipGetDevice(&dev));
+  if (dev_out) *dev_out = dev;
+  if (dev < 0 || dev >= 64) return VQ_ERR_UNSUPPORTED;
+  if (kern == nullptr) {
+    for (int i = 0; i < g_lds_n; ++i) {
+      if (g_lds[i].done[dev]) continue;
+      VQ_CHECK_HIP(hipFuncSetAttribute(g_lds[i].kern, hipFuncAttributeMaxDynamicSharedMemorySize, g_lds[i].bytes));
+      g_lds[i].done[dev] = true;
+    }
+    return VQ_OK;
+  }
+  LdsEntry* e = lds_find(kern);
+  if (e == nullptr) {            // not registered at load time (should not happen): register now
+    vq_lds_register(kern, bytes);
+    e = lds_find(kern);
+    if (e == nullptr) return vq_hip_status(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  }
+  if (!e->done[dev]) {
+    VQ_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, e->bytes));
+    e->done[dev] = true;
+  }
+  return VQ_OK;
+}

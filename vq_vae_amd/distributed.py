@@ -41,9 +41,12 @@ def make_stats_reduce(group: Optional[dist.ProcessGroup] = None, uneven_rows: bo
     bits (K) | counts high bits (K)] -- 8.06 MiB at K=8192, D=256, latency-bound on xGMI, so one
     collective instead of two is what counts for a per-GPU batch whose whole step takes half a
     millisecond.  The counts stay exact: a count c travels as c mod 4096 and c div 4096, both sums are
-    integers below 2^24 (up to 4096 ranks and 2^36 rows in total) and fp32 adds such integers
-    exactly; the hook falls back to the two-collective form beyond those limits.
-    Otherwise: an int64 all-reduce of the K counts and, in training mode, an fp32 all-reduce of dw.
+    integers below 2^24 for up to 4096 ranks of fewer than 2^24 rows each, and fp32 adds such integers
+    exactly.  Which form runs must not depend on anything that differs between ranks (ranks that
+    chose differently would issue different collectives and hang): it is decided from the world
+    size alone, and a rank holding 2^24 rows or more raises instead of switching.
+    Otherwise (``packed=False``, more than 4096 ranks, or eval mode, where there is no dw): an int64
+    all-reduce of the K counts and, in training mode, an fp32 all-reduce of dw.
     With ``uneven_rows`` the per-rank row counts are summed too (costs a host sync);
     otherwise every rank is assumed to hold the same number of rows.
     """
@@ -51,7 +54,10 @@ def make_stats_reduce(group: Optional[dist.ProcessGroup] = None, uneven_rows: bo
 
     def reduce(counts_i32: torch.Tensor, dw: Optional[torch.Tensor], n_local: int):
         world = dist.get_world_size(group)
-        if packed and dw is not None and world <= 4096 and n_local * world < (1 << 36):
+        if packed and dw is not None and world <= 4096:
+            if n_local >= 1 << 24:
+                raise ValueError(f"{n_local} rows on one rank: the packed statistics all-reduce carries counts "
+                                 "exactly below 2^24 rows per rank; split the batch or use packed=False")
             K = counts_i32.numel()
             kd = dw.numel()
             extra = 2 if uneven_rows else 0
