@@ -31,7 +31,7 @@ def rel_err(a, b):
 # Collection order under `pytest -x`: the quantizer's own parity suites come first, the optional
 # extras (boundary convolutions, filtered search, matrix-core probe) after them, so that a failure
 # in an extra cannot keep the forward / EMA / statistics rows from running.
-_ORDER = ["test_oracle_golden", "test_cabi", "test_gpu_parity", "test_gpu_module", "test_gpu_stats",
+_ORDER = ["test_oracle_golden", "test_cabi", "test_gpu_parity", "test_gpu_short_sweep", "test_gpu_module", "test_gpu_stats",
           "test_gpu_configs", "test_gpu_fullsize", "test_gpu_census", "test_gpu_boundary", "test_gpu_filtered",
           "test_gpu_filter_keys", "test_gpu_vmcnt_order"]
 _LAST = ["test_zz_no_alloc"]

@@ -7,6 +7,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // The search kernel sweeps the codebook in stages of 64 codes (two 32-row MFMA tiles).
 constexpr int VQ_STAGE_CODES = 64;
@@ -134,6 +135,9 @@ extern "C" int vq_pairwise_search_launch(const float* E, const float* image, con
                                          int64_t row_base, int64_t n_rows, float* nn_dist, int64_t* nn_idx,
                                          int32_t* idx32, double* sum_partial, float* mm_partial, int32_t* nf_rows,
                                          int32_t* control, void* stream);
+
+// Internal (not in the public header): knobs of the persistent short-sweep search (vq_search.hip).
+extern "C" int vq_internal_tune(int what, int value);
 
 // Internal (not in the public header): bf16 filter + exact verification (vq_filter.hip).
 bool vq_filter_supported(int K, int D);

@@ -43,6 +43,7 @@ struct SearchArgs {
   float* dmin;
   float* q_out;
   float* loss_partial;
+  int64_t loss_slots;   // entries of loss_partial the search itself owns (unused ones are zeroed)
   int32_t* nf_rows;
   int32_t* control;
   // pairwise mode (z := E): skip the pair (n, n); per-workgroup partials of sum/min/max
@@ -153,7 +154,8 @@ __global__ __launch_bounds__(512 / CT, 2 / CT) void vq_search_mfma_kernel(Search
 
   // A non-finite codebook sends every row to the exact kernel.
   if (a.control[VQ_CTL_CB_FLAG] != 0) {
-    if (threadIdx.x == 0 && a.loss_partial && !split) a.loss_partial[blockIdx.x] = 0.0f;
+    if (threadIdx.x == 0 && a.loss_partial && !split)
+      for (int64_t i = blockIdx.x; i < a.loss_slots || i == blockIdx.x; i += gridDim.x) a.loss_partial[i] = 0.0f;
     if (split && h == 0) {
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
@@ -413,6 +415,7 @@ __global__ __launch_bounds__(512 / CT, 2 / CT) void vq_search_mfma_kernel(Search
       if (NW == 4) tot = (red[0] + red[1]) + (red[2] + red[3]);
       else tot = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
       a.loss_partial[blockIdx.x] = tot;
+      for (int64_t i = (int64_t)blockIdx.x + gridDim.x; i < a.loss_slots; i += gridDim.x) a.loss_partial[i] = 0.0f;
     }
   }
   if (PAIRWISE) {
@@ -449,6 +452,451 @@ __global__ __launch_bounds__(512 / CT, 2 / CT) void vq_search_mfma_kernel(Search
       a.pw_minmax[2 * blockIdx.x + 1] = m1;
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// The same search for SHORT sweeps (small codebooks), where the loads of a row tile before the
+// sweep and the gather + stores after it weigh as much as the sweep itself: a persistent kernel
+// whose waves walk over many row tiles and whose two wave groups run half a period apart.
+//
+//   * One workgroup of 8 waves per CU for the whole launch.  Wave g of the grid takes the 32-row
+//     tiles g, g + G, g + 2G, ... (G = waves in the grid).
+//   * The workgroup moves in lockstep STEPS, one barrier each; step k has codebook stage
+//     k mod nstages in front of every wave.  RESIDENT: the whole image sits in LDS and stays
+//     there.  Otherwise the stages cycle through two buffers by LDS-DMA without end, stage
+//     after stage, wrapping from the last to the first.
+//   * A wave's period is X memory steps + nstages sweep steps.  Memory step m handles the m-th
+//     slice of the channels: it writes that slice of the outputs of the tile the wave has just
+//     finished (the winning code's values from the image, straight-through values,
+//     squared-difference sum), loads the same slice of its next tile into the registers this
+//     frees, and fetches the winning code's values for the next slice.  A slice is small enough
+//     (a few dozen vector-memory instructions) that the wave issues it without waiting for
+//     memory -- a wave can have 63 such instructions outstanding -- so a memory step is short
+//     and never holds up the barrier its computing partner is heading for.  Then the wave
+//     sweeps: nstages steps starting at WHATEVER stage is in front of it, wrapping around the
+//     codebook's end.
+//   * Waves 0-3 and waves 4-7 (w and w + 4 share a SIMD) run half a period apart, so while one
+//     wave of a SIMD is in its memory steps its partner is mid-sweep and has the matrix pipe to
+//     itself: loads, stores and MFMAs overlap instead of taking turns.
+//   * A sweep that starts at stage s0 > 0 sees the codes [64 s0, K) before the codes [0, 64 s0).
+//     Within each of the two runs the scan visits codes in increasing order, so '<' keeps the
+//     lowest index; the winner of the first run is set aside at the wrap and the two are merged
+//     with '<=' in favour of the second run, whose indices are all lower.  Same winner, same
+//     distance bits as the straight sweep.
+//   * LDS-DMA is issued by the waves of the group that is NOT in a memory step (its only
+//     outstanding vector-memory operations are then the DMA itself, so the vmcnt(0) before the
+//     barrier waits for nothing else); the barrier is a bare s_barrier, memory-step waves pass
+//     it with their loads and stores still in flight.
+// ---------------------------------------------------------------------------------------
+// Memory steps per period.  Image resident: 1 (the winning code's values come from LDS, the step never
+// waits for memory).  Stages cycling: 2 -- the values come from the image in global memory / L2 and are
+// fetched one step ahead, and half a tile's values are what fits beside the tile in the register file.
+// Measured at 1 Mi latents, 256 channels (K = 512 cycling: 4 steps 2.33 ms, 2 steps 2.25 ms; K = 64
+// resident: 2 steps 0.54 ms, 1 step 0.50 ms): every instruction of a memory step issues between two of
+// the partner's MFMAs, so a step costs the partner little but lasts long, and the fewer steps a wave
+// spends outside its sweep, the fewer stages its partner sweeps alone.
+#ifndef VQ_CYC_XR
+#define VQ_CYC_XR 1
+#endif
+#ifndef VQ_CYC_XS
+#define VQ_CYC_XS 2
+#endif
+__host__ __device__ constexpr int cyc_mem_steps(int D, bool resident) {
+  return resident ? VQ_CYC_XR : VQ_CYC_XS;
+}
+constexpr int VQ_CYC_WAVES = 2048;   // most waves a grid of this kernel has (256 CUs x 8): one loss partial each
+
+template <int D>
+__device__ __forceinline__ void cyc_stage_copy(const float* image, int stage, float* lds_buf, int li, int nl, int lane) {
+  constexpr int PIECES = D / 4 + 1;
+  const char* src = reinterpret_cast<const char*>(image) + (size_t)stage * vq_stage_floats(D) * 4 + lane * 16;
+  char* dst = reinterpret_cast<char*>(lds_buf);
+  for (int p = li; p < PIECES; p += nl) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)p * 1024),
+                                     (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
+  }
+}
+
+template <int M> struct CycStep { static constexpr int value = M; };
+
+// Buffer descriptor over memory starting at p: loads and stores through it are addressed as
+// "descriptor base (scalar) + scalar byte offset + this lane's 32-bit byte offset", so an access needs
+// no vector address arithmetic at all -- vector instructions are what a memory step must not spend,
+// they run on the same pipe as the partner wave's fp32 MFMAs.
+// `bytes`: what lies between p and the end of the tensor -- an access beyond it reads zero / writes nothing.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t cyc_rsrc(const void* p, int64_t bytes) {
+  const uint32_t range = bytes > 0xffffffffll ? 0xffffffffu : (bytes < 0 ? 0u : (uint32_t)bytes);
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)range, 0x00020000);
+}
+
+// Row-major latents: lane (j, 0) holds channels c .. c + 3 of its row and lane (j, 1) channels c + 4 .. c + 7
+// (one 16-byte access each); the matrix core wants the even channels in the lower lane half and the odd
+// ones in the upper.  Two half-wave swaps turn {c, c+1, c+2, c+3 | c+4, ..., c+7} into
+// {c, c+2, c+4, c+6 | c+1, c+3, c+5, c+7}; the same two swaps turn it back.
+__device__ __forceinline__ void half_interleave(f32x4& v) {
+  // swap: the upper half of the first register with the lower half of the second
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[1]), false, false);
+  auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2]), __float_as_uint(v[3]), false, false);
+  // r[0] = (c | c+1), r[1] = (c+4 | c+5), t[0] = (c+2 | c+3), t[1] = (c+6 | c+7)
+  v[0] = __uint_as_float(r[0]); v[1] = __uint_as_float(t[0]); v[2] = __uint_as_float(r[1]); v[3] = __uint_as_float(t[1]);
+}
+__device__ __forceinline__ void half_deinterleave(f32x4& v) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[2]), false, false);
+  auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[1]), __float_as_uint(v[3]), false, false);
+  // from (c | c+1), (c+4 | c+5): r[0] = (c | c+4), r[1] = (c+1 | c+5); likewise t for c+2, c+3, c+6, c+7
+  v[0] = __uint_as_float(r[0]); v[1] = __uint_as_float(r[1]); v[2] = __uint_as_float(t[0]); v[3] = __uint_as_float(t[1]);
+}
+
+// Addressing.  NCHW (H*W a multiple of 32, so a tile lies inside one image): 4-byte accesses, lane
+// (j, h) at pixel j of channel 2s + h -- 128-byte runs along the pixels.  Rows: the two lanes of a row
+// read 16 bytes each (8 consecutive channels between them) and exchange halves so that the even
+// channels end up in the lower lane half and the odd ones in the upper.  Either way the tile's base is a
+// scalar and the lane's offset from it a constant (cyc_rsrc).
+template <int D, bool NCHW, bool TEMP, bool RESIDENT>
+__global__ __launch_bounds__(512, 2) void vq_search_cyclic_kernel(SearchArgs a, int64_t ntiles) {
+  constexpr bool VEC = !NCHW;
+  constexpr int S = D / 2;
+  constexpr int G = D / 8;      // channel groups: 8 channels = 4 k-steps = one 16-byte piece of a code's image row
+  constexpr int X = cyc_mem_steps(D, RESIDENT);
+  constexpr int U = G / X;      // channel groups per memory step
+  constexpr bool PREFETCH = !RESIDENT;
+  constexpr int STAGE_F = VQ_STAGE_CODES * D + 256;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int gi = wave >> 2;                        // group: SIMD partners are waves w and w + 4
+  const int nst = a.nstages;
+  const int P = nst + X;                           // a wave's period in steps
+  const int off = gi ? P / 2 : 0;                  // group 1 runs half a period behind
+  const int64_t GW = (int64_t)gridDim.x * 8;       // waves in the grid
+  const int64_t g = (int64_t)blockIdx.x * 8 + wave;
+  const int cnt = g < ntiles ? (int)((ntiles - g + GW - 1) / GW) : 0;                    // tiles of this wave
+  const int cnt_max = (int)((ntiles - (int64_t)blockIdx.x * 8 + GW - 1) / GW);          // ... of wave 0 of this workgroup
+  const int kend = P / 2 + cnt_max * P + X;        // steps: up to group 1's last slice of its last tile
+
+  if (a.control[VQ_CTL_CB_FLAG] != 0) {
+    // a non-finite codebook sends every row to the exact kernel
+    for (int i = 0; i < cnt; ++i) {
+      const int64_t n = (g + (int64_t)i * GW) * 32 + j;
+      if (h == 0 && n < a.N) a.nf_rows[atomicAdd(&a.control[VQ_CTL_NF_COUNT], 1)] = (int32_t)n;
+    }
+    if (a.loss_partial && lane == 0)
+      for (int64_t i = g; i < a.loss_slots; i += GW) a.loss_partial[i] = 0.0f;
+    return;
+  }
+
+  // ---- prologue: the resident image, or stage 0 of the cycle (issued by group 1, which idles first)
+  if (RESIDENT) {
+    for (int st = 0; st < nst; ++st) cyc_stage_copy<D>(a.image, st, lds + (size_t)st * STAGE_F, wave, 8, lane);
+  } else if (gi == 1) {
+    cyc_stage_copy<D>(a.image, 0, lds, wave & 3, 4, lane);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+
+  float zr[S];
+  f32x4 gcur[PREFETCH ? U : 1];   // the winning code's values for the slice the next memory step writes
+  float z2 = 0.0f;
+  float best = 0.0f, best_hi = 0.0f;
+  int bidx = 0, bidx_hi = 0;
+  int win = 0;               // winner of the finished tile (both lane halves hold it)
+  bool okf = false;          // ... and whether this lane's row is a real, finite row
+  float lp = 0.0f;           // this lane's squared-difference sum over all its tiles
+  uint32_t zmax_bits = 0;
+  int64_t zo_ld = 0, zo_st = 0;   // element offset of this lane's first channel: tile being loaded / written
+
+  int s = 0;                 // stage in front of the waves: k mod nst
+  int p0 = 0;                // k mod P: group 0's phase, which decides who issues the DMA
+  int it = 0;                // tile iteration of this wave
+
+  // The winning code's values in this lane's channel order, from the image: piece gq of the code's
+  // 32-row tile holds for lane (i, h) the channels 8 gq + h + {0, 2, 4, 6}.
+  // (resident: a pointer into LDS; cycling: the lane's byte offset into the image in global memory,
+  // read through a buffer descriptor with the piece's offset as the scalar part)
+  auto code_off = [&]() __attribute__((always_inline)) -> uint32_t {
+    const int wc = okf ? win : 0;
+    return (uint32_t)(((wc >> 6) * STAGE_F + ((wc >> 5) & 1) * 32 * D) * 4 + (h * 32 + (wc & 31)) * 16);
+  };
+  const __amdgpu_buffer_rsrc_t irsrc = cyc_rsrc(a.image, (int64_t)nst * STAGE_F * 4);
+  auto code_piece = [&](uint32_t coff, int gq) __attribute__((always_inline)) -> f32x4 {
+    if (RESIDENT) return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(lds) + coff + gq * 1024);
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, coff, gq * 1024, 0));
+  };
+
+  // this lane's byte offset from the tile's base
+  const uint32_t loff = NCHW ? (uint32_t)(h * (uint32_t)a.HW + j) * 4u : (uint32_t)(j * D + 4 * h) * 4u;
+  // loads of a slice are issued in one memory step and brought into the matrix core's lane order in the
+  // next step (or at the start of the sweep), when they have long landed
+  auto finish_loads = [&](auto mtag) __attribute__((always_inline)) {
+    constexpr int M = decltype(mtag)::value;
+    if (!VEC) return;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int gq = M * U + u;
+      f32x4 v = {zr[4 * gq], zr[4 * gq + 1], zr[4 * gq + 2], zr[4 * gq + 3]};
+      half_interleave(v);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) zr[4 * gq + q] = v[q];
+      if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  auto mem_step = [&](auto mtag) __attribute__((always_inline)) {
+    constexpr int M = decltype(mtag)::value;
+    const bool have_prev = it >= 1 && it <= cnt && a.q_out != nullptr;
+    const bool have_next = it < cnt;
+    const uint32_t coff = code_off();
+    if (M == 0) {
+      if (PREFETCH && have_prev) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) gcur[u] = code_piece(coff, u);
+      }
+      zo_st = zo_ld;
+      if (it < cnt) {
+        const uint32_t tile = (uint32_t)(g + (int64_t)it * GW);
+        if (NCHW) {
+          const uint32_t tpi = (uint32_t)(a.HW >> 5);           // tiles per image
+          const uint32_t img = tile / tpi;
+          zo_ld = (int64_t)img * D * a.HW + (int64_t)(tile - img * tpi) * 32;
+        } else {
+          // (rows past the end of the last tile: their loads fall into the next rows of the buffer or are
+          // clipped by the descriptor's range; their outputs are never written)
+          zo_ld = (int64_t)tile * 32 * D;
+        }
+      }
+    }
+    if (M >= 1 && have_next) finish_loads(CycStep<(M + X - 1) % X>{});
+    // bytes between this lane's consecutive values (NCHW) or consecutive 16-byte pieces (rows)
+    uint32_t bstride = NCHW ? (uint32_t)(2 * a.HW * 4) : 32u;
+    // opaque: keeps the channel offsets from being computed once, outside the step loop, and held in
+    // scalar registers for the whole launch
+    if (NCHW) asm volatile("" : "+s"(bstride));
+    if (have_prev) {
+      const int64_t nprev = (g + (int64_t)(it - 1) * GW) * 32 + j;
+      const bool valid = nprev < a.N;
+      const __amdgpu_buffer_rsrc_t orsrc = cyc_rsrc(a.q_out + zo_st, (a.N * D - zo_st) * 4);
+      float part = 0.0f;
+      if (VEC) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int gq = M * U + u;
+          const f32x4 ev = PREFETCH ? gcur[u] : code_piece(coff, gq);
+          f32x4 o;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float d0 = ev[q] - zr[4 * gq + q];
+            part = __builtin_fmaf(d0, d0, part);
+            o[q] = zr[4 * gq + q] + d0;
+          }
+          half_deinterleave(o);
+          // a row is written whole: rows that are not finite get their values from the exact kernel
+          // afterwards; rows past the end are not written
+          if (valid) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), orsrc, loff, gq * bstride, 0);
+        }
+      } else if (okf) {   // one predicated region: rows past the end and non-finite rows write nothing
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int gq = M * U + u;
+          const f32x4 ev = PREFETCH ? gcur[u] : code_piece(coff, gq);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float d0 = ev[q] - zr[4 * gq + q];
+            part = __builtin_fmaf(d0, d0, part);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, zr[4 * gq + q] + d0), orsrc, loff,
+                                                  (4 * gq + q) * bstride, 0);
+          }
+        }
+      }
+      lp += okf ? part : 0.0f;
+    }
+    if (have_next) {
+      const __amdgpu_buffer_rsrc_t zrsrc = cyc_rsrc(a.z + zo_ld, (a.N * D - zo_ld) * 4);
+      if (VEC) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int gq = M * U + u;
+          const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zrsrc, loff, gq * bstride, 0));
+#pragma unroll
+          for (int q = 0; q < 4; ++q) zr[4 * gq + q] = v[q];
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            zr[4 * (M * U + u) + q] = __builtin_bit_cast(
+                float, __builtin_amdgcn_raw_buffer_load_b32(zrsrc, loff, (4 * (M * U + u) + q) * bstride, 0));
+      }
+    }
+    if (PREFETCH && M + 1 < X && have_prev) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) gcur[u] = code_piece(coff, (M + 1) * U + u);
+    }
+  };
+
+  // Every wave runs the same number of steps (kend), one barrier each.  step_begin issues the DMA
+  // of the next stage if this wave's group is the one to do so and names the buffer of the stage
+  // in front; step_end is the barrier.
+  int k = 0;
+  bool issuer = false;
+  const float* buf = lds;
+  auto dma_issue = [&]() __attribute__((always_inline)) {
+    if (!RESIDENT && issuer && k + 1 < kend)
+      cyc_stage_copy<D>(a.image, s + 1 == nst ? 0 : s + 1, lds + (size_t)((k + 1) & 1) * STAGE_F, wave & 3, 4, lane);
+  };
+  // defer_dma: the caller issues the DMA itself, later in the step (a sweeping wave does so between its
+  // two halves: at the start of a step the memory-step waves send their loads and stores, and a DMA
+  // instruction queued behind that burst would hold up the MFMAs behind it in this wave's stream)
+  auto step_begin = [&](bool defer_dma) __attribute__((always_inline)) {
+    if (!RESIDENT) {
+      issuer = gi == (p0 < X ? 1 : 0);
+      buf = lds + (size_t)(k & 1) * STAGE_F;
+      if (!defer_dma) dma_issue();
+    } else {
+      buf = lds + (size_t)s * STAGE_F;
+    }
+  };
+  auto step_end = [&]() __attribute__((always_inline)) {
+    if (!RESIDENT && issuer) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the DMA of the next stage has landed
+    __builtin_amdgcn_s_waitcnt(0xC07F);                            // lgkmcnt(0): this wave is done reading buf
+    __builtin_amdgcn_s_barrier();
+    ++k;
+    if (++s == nst) s = 0;
+    if (++p0 == P) p0 = 0;
+  };
+
+  for (int i = 0; i < off; ++i) { step_begin(false); step_end(); }   // group 1: half a period behind
+
+  for (it = 0; it <= cnt_max; ++it) {
+    // ================= memory steps: slice by slice, the outputs of tile it-1 and the loads of tile it
+    // A memory step is a few hundred vector and scalar instructions beside the partner's MFMAs.  At equal
+    // priority the arbiter keeps offering the slot to the wave whose next MFMA is waiting for the pipe,
+    // and this wave's instructions trickle out at about one per MFMA; with priority they issue back to
+    // back, and the partner still gets the one slot per 64 cycles its MFMAs need.
+    __builtin_amdgcn_s_setprio(3);
+    step_begin(false); if (it <= cnt) mem_step(CycStep<0>{}); step_end();
+    if (X >= 2) { step_begin(false); if (it <= cnt) mem_step(CycStep<1 % X>{}); step_end(); }
+    if (X >= 4) {
+      step_begin(false); if (it <= cnt) mem_step(CycStep<2 % X>{}); step_end();
+      step_begin(false); if (it <= cnt) mem_step(CycStep<3 % X>{}); step_end();
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (it == cnt_max) break;
+
+    // ================= sweep steps: the stage in front against this wave's tile ================
+    for (int c = 0; c < nst; ++c) {
+      step_begin(it < cnt);
+      if (it < cnt) {
+      if (c == 0) {
+        finish_loads(CycStep<X - 1>{});   // the last slice of the tile's loads
+        float p = 0.0f;
+        uint32_t am = 0;
+#pragma unroll
+        for (int sI = 0; sI < S; ++sI) {
+          p = __builtin_fmaf(zr[sI], zr[sI], p);
+          const uint32_t ab = __float_as_uint(zr[sI]) & 0x7fffffffu;
+          am = ab > am ? ab : am;
+        }
+        zmax_bits = am > zmax_bits ? am : zmax_bits;
+        z2 = p + __shfl_xor(p, 32);  // even-channel chain + odd-channel chain
+        best = __builtin_inff(); bidx = 0;
+        best_hi = __builtin_inff(); bidx_hi = 0;
+      } else if (s == 0) {
+        // wrapped around the end of the codebook: what was seen so far has the higher indices
+        best_hi = best; bidx_hi = bidx;
+        best = __builtin_inff(); bidx = 0;
+      }
+      f32x16 cA, cB;
+      const f32x4* A = reinterpret_cast<const f32x4*>(buf) + lane;
+      const f32x4* e2s = reinterpret_cast<const f32x4*>(buf + VQ_STAGE_CODES * D) + h;
+      double pd = 0.0; float pf0 = 0.0f, pf1 = 0.0f;   // unused outputs of scan_tile
+
+      // first half: codes [64 s, 64 s + 32) into set A
+#pragma unroll
+      for (int i = 0; i < 16; ++i) cA[i] = 0.0f;
+      {
+        f32x4 af = A[0];
+#pragma unroll
+        for (int gq = 0; gq < G; ++gq) {
+          const f32x4 an = A[(gq + 1 < G ? gq + 1 : gq) * 64];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) cA = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], zr[4 * gq + q], cA, 0, 0, 0);
+          af = an;
+        }
+      }
+      dma_issue();   // (deferred from the start of the step)
+      // second half: codes [64 s + 32, 64 s + 64) into set B; the scan of set A falls under its MFMAs
+#pragma unroll
+      for (int i = 0; i < 16; ++i) cB[i] = 0.0f;
+      {
+        f32x4 af = A[G * 64];
+#pragma unroll
+        for (int gq = 0; gq < G; ++gq) {
+          const f32x4 an = A[(G + (gq + 1 < G ? gq + 1 : gq)) * 64];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) cB = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], zr[4 * gq + q], cB, 0, 0, 0);
+          af = an;
+        }
+      }
+      {
+        f32x4 e2A[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e2A[q] = e2s[2 * q];
+        scan_tile<TEMP, false>(cA, e2A, z2, s * VQ_STAGE_CODES, a.T, -1, best, bidx, pd, pf0, pf1);
+      }
+      {
+        f32x4 e2B[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e2B[q] = e2s[8 + 2 * q];
+        scan_tile<TEMP, false>(cB, e2B, z2, s * VQ_STAGE_CODES + 32, a.T, -1, best, bidx, pd, pf0, pf1);
+      }
+
+      if (c == nst - 1) {
+        // ---- the tile is swept: merge of the two runs and of the two lane halves ----------------
+        if (!(best <= best_hi)) { best = best_hi; bidx = bidx_hi; }
+        int bi = bidx + 4 * h;
+        float b = best;
+        const float ob = __shfl_xor(b, 32);
+        const int oi = __shfl_xor(bi, 32);
+        const bool take = (ob < b) || (ob == b && oi < bi);
+        b = take ? ob : b;
+        bi = take ? oi : bi;
+        const int64_t n = (g + (int64_t)it * GW) * 32 + j;
+        const bool valid = n < a.N;
+        okf = valid && z2 <= VQ_NORM_LIMIT;   // false for NaN
+        win = bi;
+        if (h == 0) {
+          if (okf) {
+            if (a.idx64) a.idx64[n] = (int64_t)bi + a.code_base;
+            if (a.idx32) a.idx32[n] = (int32_t)(bi + a.code_base);
+            if (a.dmin) a.dmin[n] = b;
+          } else if (valid) {
+            a.nf_rows[atomicAdd(&a.control[VQ_CTL_NF_COUNT], 1)] = (int32_t)n;
+          }
+        }
+      }
+      }
+      step_end();
+    }
+  }
+  while (k < kend) { step_begin(false); step_end(); }   // group 0 keeps the barriers company to the end
+
+  // ---- one loss partial per wave (the tiles of a wave in order, then a fixed tree: reproducible) ----
+  if (a.q_out != nullptr && a.loss_partial != nullptr) {
+    const float ws = wave_sum(lp);
+    if (lane == 0) {
+      a.loss_partial[g] = ws;
+      for (int64_t i = g + GW; i < a.loss_slots; i += GW) a.loss_partial[i] = 0.0f;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const uint32_t ov = (uint32_t)__shfl_xor((int)zmax_bits, o);
+    zmax_bits = ov > zmax_bits ? ov : zmax_bits;
+  }
+  if (lane == 0 && zmax_bits) atomicMax(reinterpret_cast<unsigned int*>(&a.control[VQ_CTL_ZMAX]), zmax_bits);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1155,7 +1603,8 @@ __global__ __launch_bounds__(256) void vq_gather_st_kernel(const float* __restri
                                                            int64_t HW, const float* __restrict__ E, int K,
                                                            const int64_t* __restrict__ idx, float* __restrict__ q_out,
                                                            float* __restrict__ loss_partial,
-                                                           const int32_t* __restrict__ gate_control) {
+                                                           const int32_t* __restrict__ gate_control,
+                                                           int64_t loss_slots) {
   // A workgroup owns 256 consecutive rows.  NCHW: thread = row, loop over channels, so the
   // z loads and q stores of a wave are contiguous along hw; the codebook rows come through
   // the caches.  ND: a wave walks one row at a time, lanes along channels.
@@ -1165,7 +1614,8 @@ __global__ __launch_bounds__(256) void vq_gather_st_kernel(const float* __restri
   float part = 0.0f;
   if (gate_control != nullptr && vq_filter_gave_up(gate_control, N)) {
     // filtered search that fell back to the fp32 kernel: that kernel writes every row itself
-    if (t == 0 && loss_partial) loss_partial[blockIdx.x] = 0.0f;
+    if (t == 0 && loss_partial)
+      for (int64_t i = blockIdx.x; i < loss_slots || i == blockIdx.x; i += gridDim.x) loss_partial[i] = 0.0f;
     return;
   }
   if (nchw) {
@@ -1219,7 +1669,10 @@ __global__ __launch_bounds__(256) void vq_gather_st_kernel(const float* __restri
   const float ws = wave_sum(part);
   if (lane == 0) red[wave] = ws;
   __syncthreads();
-  if (t == 0 && loss_partial) loss_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (t == 0 && loss_partial) {
+    loss_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    for (int64_t i = (int64_t)blockIdx.x + gridDim.x; i < loss_slots; i += gridDim.x) loss_partial[i] = 0.0f;
+  }
 }
 
 template <int D, int CT, bool NCHW, bool TEMP, bool PAIRWISE>
@@ -1255,6 +1708,88 @@ int run_mfma(const SearchArgs& a, int D, bool nchw, bool temp, bool pairwise, hi
     case 64: return dispatch_mfma<64>(a, nchw, temp, pairwise, s);
     case 128: return dispatch_mfma<128>(a, nchw, temp, pairwise, s);
     case 256: return dispatch_mfma<256>(a, nchw, temp, pairwise, s);
+    default: return VQ_ERR_UNSUPPORTED;
+  }
+}
+
+// Loss partials the search itself owns: one per 256-row workgroup, or, for batches the persistent
+// kernel may take (one partial per wave of its grid), at least as many as that grid has waves.
+int64_t loss_slots_for(int64_t N) {
+  const int64_t blocks = N > 0 ? (N + VQ_WG_ROWS - 1) / VQ_WG_ROWS : 0;
+  return blocks >= 512 && blocks < VQ_CYC_WAVES ? VQ_CYC_WAVES : blocks;
+}
+
+// ---- the persistent kernel for short sweeps: when it runs, and how ---------------------------
+struct CyclicTune {
+  int enable = 1;
+  int max_stages = 16;          // K <= 1024: beyond that the one-tile-per-workgroup kernel is as fast
+  int64_t min_tiles_per_wave = 2;
+  int force_streaming = 0;      // never keep the image resident (experiments)
+};
+CyclicTune g_cyc;
+
+
+constexpr int CYC_LDS_MAX = 160 * 1024;
+
+bool cyc_resident(int nstages, int D) {
+  return !g_cyc.force_streaming && (size_t)nstages * vq_stage_floats(D) * 4 + 256 <= (size_t)CYC_LDS_MAX;
+}
+
+int device_cus(int dev) {
+  static int cus[64] = {};
+  if (dev < 0 || dev >= 64) return 256;
+  if (!cus[dev] && hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus[dev] = 256;
+  return cus[dev];
+}
+
+bool cyc_eligible(int64_t N, int K, int D, bool nchw, int64_t HW) {
+  if (!g_cyc.enable) return false;
+  if (nchw && HW % 32 != 0) return false;      // a 32-row tile must lie inside one image
+  if (loss_slots_for(N) < VQ_CYC_WAVES) return false;   // one loss partial per wave of the grid
+  const int nstages = vq_kpad(K) / VQ_STAGE_CODES;
+  if (nstages > g_cyc.max_stages) return false;
+  const int64_t ntiles = (N + 31) / 32;
+  if (ntiles < g_cyc.min_tiles_per_wave * VQ_CYC_WAVES) return false;
+  // cycling stages: the two groups' memory steps must not overlap, or nobody is left to issue the DMA
+  if (!cyc_resident(nstages, D) && nstages < cyc_mem_steps(D, false) + 1) return false;
+  return true;
+}
+
+template <int D, bool NCHW, bool TEMP, bool RESIDENT>
+int launch_cyclic(const SearchArgs& a, hipStream_t s) {
+  constexpr int attr_bytes = RESIDENT ? CYC_LDS_MAX : (int)(2 * vq_stage_floats(D) * 4 + 256);
+  int dev = 0;
+  const int arc = vq_lds_ready<vq_search_cyclic_kernel<D, NCHW, TEMP, RESIDENT>, attr_bytes>(&dev);
+  if (arc != VQ_OK) return arc;
+  const size_t lds_bytes = RESIDENT ? (size_t)a.nstages * vq_stage_floats(D) * 4 + 256 : (size_t)attr_bytes;
+  const int64_t ntiles = (a.N + 31) / 32;
+  int64_t grid = device_cus(dev);
+  if (grid > VQ_CYC_WAVES / 8) grid = VQ_CYC_WAVES / 8;
+  if (grid > (ntiles + 7) / 8) grid = (ntiles + 7) / 8;
+  hipLaunchKernelGGL((vq_search_cyclic_kernel<D, NCHW, TEMP, RESIDENT>), dim3((unsigned)grid), dim3(512), lds_bytes,
+                     s, a, ntiles);
+  return vq_hip_status(hipGetLastError());
+}
+
+template <int D, bool NCHW>
+int dispatch_cyclic2(const SearchArgs& a, bool temp, hipStream_t s) {
+  const bool res = cyc_resident(a.nstages, D);
+  if (temp) return res ? launch_cyclic<D, NCHW, true, true>(a, s) : launch_cyclic<D, NCHW, true, false>(a, s);
+  return res ? launch_cyclic<D, NCHW, false, true>(a, s) : launch_cyclic<D, NCHW, false, false>(a, s);
+}
+
+template <int D>
+int dispatch_cyclic(const SearchArgs& a, bool nchw, bool temp, hipStream_t s) {
+  return nchw ? dispatch_cyclic2<D, true>(a, temp, s) : dispatch_cyclic2<D, false>(a, temp, s);
+}
+
+int run_cyclic(const SearchArgs& a, int D, bool nchw, bool temp, hipStream_t s) {
+  switch (D) {
+    case 16: return dispatch_cyclic<16>(a, nchw, temp, s);
+    case 32: return dispatch_cyclic<32>(a, nchw, temp, s);
+    case 64: return dispatch_cyclic<64>(a, nchw, temp, s);
+    case 128: return dispatch_cyclic<128>(a, nchw, temp, s);
+    case 256: return dispatch_cyclic<256>(a, nchw, temp, s);
     default: return VQ_ERR_UNSUPPORTED;
   }
 }
@@ -1321,7 +1856,22 @@ size_t vq_image_bytes(int K, int D) {
 }
 size_t vq_norms_bytes(int K) { return K > 0 ? (size_t)vq_kpad(K) * 4 : 256; }
 int64_t vq_search_blocks(int64_t N) { return N > 0 ? (N + VQ_WG_ROWS - 1) / VQ_WG_ROWS : 0; }
-size_t vq_loss_partial_bytes(int64_t N) { return (size_t)(vq_search_blocks(N) + VQ_FIX_WGS) * 4; }
+static int64_t loss_slots(int64_t N) { return loss_slots_for(N); }
+size_t vq_loss_partial_bytes(int64_t N) { return (size_t)(loss_slots(N) + VQ_FIX_WGS) * 4; }
+
+// Internal (not in the public header): knobs of the persistent short-sweep kernel, for experiments
+// and A/B timing.  what: 0 enable, 1 max stages, 2 min tiles per wave, 4 force cycling stages.  Returns the previous value.
+int vq_internal_tune(int what, int value) {
+  int old = -1;
+  switch (what) {
+    case 0: old = g_cyc.enable; g_cyc.enable = value; break;
+    case 1: old = g_cyc.max_stages; g_cyc.max_stages = value; break;
+    case 2: old = (int)g_cyc.min_tiles_per_wave; g_cyc.min_tiles_per_wave = value; break;
+    case 4: old = g_cyc.force_streaming; g_cyc.force_streaming = value; break;
+    default: break;
+  }
+  return old;
+}
 size_t vq_control_bytes(void) { return VQ_CTL_WORDS * 4; }
 
 int vq_control_reset(int32_t* control, void* stream) {
@@ -1365,6 +1915,8 @@ static int search_common(const float* z, int layout, int64_t N, int D, int64_t H
   a.idx64 = idx64; a.idx32 = idx32; a.dmin = dmin; a.q_out = q_out; a.loss_partial = loss_partial;
   a.nf_rows = nf_rows; a.control = control;
   const int64_t blocks = vq_search_blocks(N);
+  const int64_t slots = loss_slots(N);
+  a.loss_slots = slots;
   // T > 0 and finite keeps the MFMA path (division by it is monotone); anything else is
   // evaluated literally by the exact kernel.
   const bool t_regular = temperature > 0.0f && temperature < __builtin_inff();
@@ -1389,27 +1941,31 @@ static int search_common(const float* z, int layout, int64_t N, int D, int64_t H
                          sp.ksplit, N, idx64, idx32, dmin);
       if (q_out) {
         hipLaunchKernelGGL(vq_gather_st_kernel, dim3((unsigned)blocks), dim3(256), 0, s, z, nchw ? 1 : 0, N, D, a.HW,
-                           E, K, idx64, q_out, loss_partial, (const int32_t*)nullptr);
+                           E, K, idx64, q_out, loss_partial, (const int32_t*)nullptr, slots);
       }
       VQ_CHECK_HIP(hipGetLastError());
       a.q_out = q_out;
       a.loss_partial = loss_partial;
       a.ksplit = 1;
+    } else if (cyc_eligible(N, K, D, nchw, a.HW)) {
+      // short sweep, large batch: the persistent kernel (same winners, distances and outputs)
+      rc = run_cyclic(a, D, nchw, temperature != 1.0f, s);
+      if (rc != VQ_OK) return rc;
     } else {
       rc = run_mfma(a, D, nchw, temperature != 1.0f, false, s);
       if (rc != VQ_OK) return rc;
     }
     // rows flagged by the MFMA kernel (normally none: the kernel then exits at once)
-    float* fix_loss = loss_partial ? loss_partial + blocks : nullptr;
+    float* fix_loss = loss_partial ? loss_partial + slots : nullptr;
     return run_exact(a, D, nchw, true, fix_loss, VQ_FIX_WGS, s);
   }
-  // exact path for everything: partials [0, blocks) are zeroed, the kernel fills the tail
-  if (loss_partial) VQ_CHECK_HIP(hipMemsetAsync(loss_partial, 0, (size_t)blocks * 4, s));
+  // exact path for everything: the search's own partials are zeroed, the kernel fills the tail
+  if (loss_partial) VQ_CHECK_HIP(hipMemsetAsync(loss_partial, 0, (size_t)slots * 4, s));
   if (control) {
     int rc = vq_launch_absmax(z, N * D, control, s);
     if (rc != VQ_OK) return rc;
   }
-  float* fix_loss = loss_partial ? loss_partial + blocks : nullptr;
+  float* fix_loss = loss_partial ? loss_partial + slots : nullptr;
   return run_exact(a, D, nchw, false, fix_loss, VQ_FIX_WGS, s);
 }
 
@@ -1450,7 +2006,7 @@ int vq_search_filtered(const float* z, int layout, int64_t N, int D, int64_t HW,
   if (q_out) {
     // 2. settled rows: gather + straight-through + loss partials (rows marked -1 are skipped)
     hipLaunchKernelGGL(vq_gather_st_kernel, dim3((unsigned)blocks), dim3(256), 0, s, z, nchw ? 1 : 0, N, D,
-                       nchw ? HW : 1, E, K, idx64, q_out, loss_partial, (const int32_t*)control);
+                       nchw ? HW : 1, E, K, idx64, q_out, loss_partial, (const int32_t*)control, (int64_t)0);
     VQ_CHECK_HIP(hipGetLastError());
   }
   SearchArgs a{};
@@ -1491,7 +2047,7 @@ int vq_gather_st(const float* z, int layout, int64_t N, int D, int64_t HW, const
   const int64_t blocks = vq_search_blocks(N);
   hipLaunchKernelGGL(vq_gather_st_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, z,
                      layout == VQ_LAYOUT_NCHW ? 1 : 0, N, D, layout == VQ_LAYOUT_NCHW ? HW : 1, E, K, idx64, q_out,
-                     loss_partial, (const int32_t*)nullptr);
+                     loss_partial, (const int32_t*)nullptr, (int64_t)0);
   return vq_hip_status(hipGetLastError());
 }
 
