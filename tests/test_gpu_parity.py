@@ -282,11 +282,15 @@ def test_training_trajectory(K, D, shape, decay, beta, T, dev, ops):
 
 @pytest.mark.parametrize("K,D,shape", [
     (1, 16, (1, 16, 2, 3)),          # a single code: every row picks it
-    (2, 8, (3, 8, 1, 5)),            # D = 8: exact kernel
+    (2, 8, (3, 8, 1, 5)),            # D = 8: matrix cores at 16 channels, 8 of them zero
     (3, 1, (2, 1, 4, 4)),            # one channel
     (65, 16, (1, 16, 1, 1)),         # one row, one code beyond a stage
     (33, 32, (700, 32)),             # row-major, ragged everything
-    (7, 100, (2, 100, 3, 3)),        # channel count outside the matrix-core set
+    (7, 100, (2, 100, 3, 3)),        # channel count outside the kernels' own set: zero-padded to 128
+    (1000, 48, (9, 48, 16, 16)),     # 48 channels as 64, a ragged last stage
+    (300, 49, (2, 49, 7, 9)),        # an odd channel count
+    (64, 200, (500, 200)),           # row-major rows of 800 bytes, padded to 256 channels
+    (130, 255, (3, 255, 4, 4)),      # one channel short of 256
     (4096, 128, (1, 128, 16, 17)),   # HW = 272 (not a multiple of 32), codebook split of a small batch
 ])
 def test_edge_shapes_two_training_steps(K, D, shape, dev, ops):
@@ -382,3 +386,34 @@ def test_documented_ctypes_binding(dev):
     finally:
         os.chdir(cwd)
     assert np.array_equal(idx.cpu().numpy(), vo.search(z, E)[0])
+
+
+@pytest.mark.parametrize("K,D,shape", [(1000, 48, (16, 48, 16, 16)), (7, 100, (3, 100, 5, 5)), (300, 49, (700, 49)),
+                                       (96, 17, (2, 17, 8, 8)), (513, 130, (4, 130, 6, 6))])
+@pytest.mark.parametrize("T", [1.0, 2.5])
+def test_zero_padded_channel_counts_run_on_the_matrix_cores(K, D, shape, T, dev, ops):
+    """Any embedding_dim up to 256 (vqvae/ema_vector_quantizer.py:11 takes any): counts other than 16 / 32 / 64 /
+    128 / 256 run at the next of those with zero channels.  Same indices, distances and outputs, bit for bit, as the
+    exact scalar kernel and the oracle."""
+    z = gauss(1701, shape)
+    E = gauss(1702, (K, D)) * np.float32(0.6)
+    ws = ops.Workspace(dev)
+    zt, Et = _t(z, dev), _t(E, dev)
+    fast = ops.search(zt, Et, ws, temperature=T, want_quantized=True, want_dmin=True)
+    lp_fast = float(fast["loss_partial"][: fast["n_partial"]].double().sum())
+    i_f, d_f, q_f = fast["indices"].clone(), fast["dmin"].clone(), fast["quantized"].clone()
+    exact = ops.search(zt, Et, ws, temperature=T, want_quantized=True, want_dmin=True, exact=True)
+    lp_exact = float(exact["loss_partial"][: exact["n_partial"]].double().sum())
+    torch.cuda.synchronize()
+    assert torch.equal(i_f, exact["indices"])
+    assert torch.equal(d_f.view(torch.int32), exact["dmin"].view(torch.int32))
+    assert torch.equal(q_f.view(torch.int32), exact["quantized"].view(torch.int32))
+    assert abs(lp_fast - lp_exact) <= 1e-6 * abs(lp_exact)
+    o_idx, o_d = vo.search(z, E, T)
+    assert np.array_equal(i_f.cpu().numpy(), o_idx)
+    assert np.array_equal(_bits(d_f.cpu().numpy()), _bits(o_d))
+    # the library really took the matrix-core path: the image of a D-channel codebook is laid out at the next size up
+    from vq_vae_amd._lib import load
+    lib = load()
+    dp = next(p for p in (16, 32, 64, 128, 256) if p >= D)
+    assert lib.vq_image_bytes(K, D) == lib.vq_image_bytes(K, dp) > 256

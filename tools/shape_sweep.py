@@ -29,7 +29,7 @@ def main():
     N = 1 << 20
     g = torch.Generator(device=dev).manual_seed(0)
     print("K, D: fp32 search ms (TFLOP/s, M vectors/s) | filtered search ms")
-    for K, D in ((64, 256), (512, 256), (2048, 256), (8192, 256), (512, 64), (8192, 64), (8192, 128), (1000, 48)):
+    for K, D in ((64, 256), (512, 256), (2048, 256), (8192, 256), (512, 64), (8192, 64), (8192, 128), (1000, 48), (512, 100), (8192, 200)):
         z = torch.randn(N // 1024, D, 32, 32, device=dev, generator=g)
         E = torch.randn(K, D, device=dev, generator=g)
         ms = timed(lambda: ops.search(z, E, ws, want_quantized=True))

@@ -26,6 +26,12 @@ __host__ __device__ inline int vq_kpad(int K) { return (K + VQ_STAGE_CODES - 1) 
 __host__ __device__ constexpr size_t vq_stage_floats(int D) { return (size_t)VQ_STAGE_CODES * D + 256; }
 
 __host__ __device__ inline bool vq_fast_dim(int D) { return D == 16 || D == 32 || D == 64 || D == 128 || D == 256; }
+// Channel count the matrix-core kernels run a D-channel problem at: D itself when it is one of the five
+// above, otherwise the next one up with the extra channels zero (0 beyond 256: no matrix-core path).
+// Zero channels change nothing: fma(0, 0, acc) = acc bit for bit (a chain that starts at +0 never holds -0).
+__host__ __device__ inline int vq_pad_dim(int D) {
+  return D <= 0 ? 0 : D <= 16 ? 16 : D <= 32 ? 32 : D <= 64 ? 64 : D <= 128 ? 128 : D <= 256 ? 256 : 0;
+}
 
 // Control words shared by the kernels of one step (device memory, 16 ints).
 enum { VQ_CTL_NF_COUNT = 0, VQ_CTL_CB_FLAG = 1, VQ_CTL_BAD_INDEX = 2, VQ_CTL_ZMAX = 3, VQ_CTL_OVF_COUNT = 4, VQ_CTL_OVF2_COUNT = 5, VQ_CTL_WORDS = 16 };

@@ -35,6 +35,7 @@ struct SearchArgs {
   int64_t N;
   int64_t HW;
   int K;
+  int Dreal;            // channels of z and E in memory (the kernels' template D when no padding is involved)
   int nstages;
   float T;
   int64_t code_base;
@@ -132,7 +133,9 @@ __device__ __forceinline__ void scan_tile(const f32x16& c, const f32x4 (&e2v)[4]
 // CT = 32-latent column tiles per wave.  CT = 2: 4 waves, one per SIMD, 512 registers each.
 // CT = 1: 8 waves, two per SIMD, 256 registers each -- the partner wave's MFMAs cover a wave's
 // scan, DMA issue and LDS waits.
-template <int D, int CT, bool NCHW, bool TEMP, bool PAIRWISE>
+// PAD: z and E have a.Dreal < D channels in memory; the image carries zeros in channels Dreal .. D-1, the
+// tile's registers for those channels are zero, and the tail takes the winning code's values from the image.
+template <int D, int CT, bool NCHW, bool TEMP, bool PAIRWISE, bool PAD = false>
 __global__ __launch_bounds__(512 / CT, 2 / CT) void vq_search_mfma_kernel(SearchArgs a) {
   constexpr int NW = 8 / CT;  // waves per workgroup
   constexpr int S = D / 2;  // k-steps of the 32x32x2 MFMA
@@ -187,7 +190,23 @@ __global__ __launch_bounds__(512 / CT, 2 / CT) void vq_search_mfma_kernel(Search
     int64_t n = row0 + ct * 32 + j;
     if (n >= a.N) n = a.N - 1;  // clamped duplicate: loads stay in bounds, outputs are masked
     float p = 0.0f;
-    if (NCHW) {
+    if (PAD) {
+      // element (channel c) of row n sits at zoff + c * cs; channels beyond Dreal read as zero
+      const int64_t cs = NCHW ? a.HW : 1;
+      if (NCHW) {
+        const int64_t b = n / a.HW, hw = n - b * a.HW;
+        zoff[ct] = b * a.Dreal * a.HW + hw;
+      } else {
+        zoff[ct] = n * a.Dreal;
+      }
+      const float* src = a.z + zoff[ct];
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const int c = 2 * s + h;
+        const float v = src[(int64_t)(c < a.Dreal ? c : a.Dreal - 1) * cs];
+        zr[ct][s] = c < a.Dreal ? v : 0.0f;
+      }
+    } else if (NCHW) {
       const int64_t b = n / a.HW, hw = n - b * a.HW;
       zoff[ct] = (b * D + h) * a.HW + hw;
       const float* src = a.z + zoff[ct];
@@ -377,7 +396,28 @@ __global__ __launch_bounds__(512 / CT, 2 / CT) void vq_search_mfma_kernel(Search
     }
 
     // ---- gather E[bi], straight-through output, squared-difference sum -------------------
-    if (a.q_out != nullptr) {
+    if (PAD && a.q_out != nullptr) {
+      // the winning code's values in this lane's channel order, from the image (in global memory): piece
+      // g of the code's 32-row tile holds for lane (i, h) the channels 8 g + h + {0, 2, 4, 6}
+      const int wc = ok ? bi : 0;
+      const f32x4* irow = reinterpret_cast<const f32x4*>(a.image + (size_t)(wc >> 6) * STAGE_F + (size_t)((wc >> 5) & 1) * 32 * D) +
+                          (h * 32 + (wc & 31));
+      const int64_t cs = NCHW ? a.HW : 1;
+      float* obase = a.q_out + zoff[ct];
+      float part = 0.0f;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const f32x4 v = irow[g * 64];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = 8 * g + 2 * q + h;
+          const float d0 = v[q] - zr[ct][4 * g + q];
+          part = __builtin_fmaf(d0, d0, part);      // zero channels add nothing
+          if (ok && c < a.Dreal) obase[(int64_t)c * cs] = zr[ct][4 * g + q] + d0;
+        }
+      }
+      lp += ok ? part : 0.0f;
+    } else if (a.q_out != nullptr) {
       const f32x4* erow = reinterpret_cast<const f32x4*>(a.E + (size_t)(ok ? bi : 0) * D);
       float* obase = a.q_out + zoff[ct];
       float part = 0.0f;
@@ -1511,11 +1551,13 @@ __global__ __launch_bounds__(256) void vq_search_rows_kernel(SearchArgs a, int D
 // One wave per 32-code tile; lane (i = lane&31, h = lane>>5) walks row i's channels 2s+h,
 // which is both the even/odd norm chain and the A-operand element order.
 // ---------------------------------------------------------------------------------------
+// Dreal: channels of a row of E in memory; Dreal < D lays the image out at D channels with zeros in
+// channels Dreal .. D-1 (the norms, chains over the even and over the odd channels, are unchanged by them).
 template <int D>
 __global__ __launch_bounds__(64) void vq_prep_image_kernel(const float* __restrict__ E, int K, float* __restrict__ image,
                                                            float* __restrict__ e2, int32_t* control,
                                                            const float* __restrict__ bias = nullptr,
-                                                           int conv_image = 0) {
+                                                           int conv_image = 0, int Dreal = D) {
   constexpr int G = D / 8;
   const int lane = threadIdx.x;
   const int i = lane & 31, h = lane >> 5;
@@ -1523,19 +1565,28 @@ __global__ __launch_bounds__(64) void vq_prep_image_kernel(const float* __restri
   const int code = tile * 32 + i;
   const bool real = code < K;
   const f32x4* row = reinterpret_cast<const f32x4*>(E + (size_t)(real ? code : 0) * D);
+  const float* srow = E + (size_t)(real ? code : 0) * Dreal;
   const int stage = tile >> 1, rt = tile & 1;
   float* st_base = image + (size_t)stage * vq_stage_floats(D);
   f32x4* dst = reinterpret_cast<f32x4*>(st_base + (size_t)rt * 32 * D) + lane;
   float p = 0.0f;
 #pragma unroll
   for (int g = 0; g < G; ++g) {
-    f32x4 v0 = row[2 * g], v1 = row[2 * g + 1];
-    if (!real) { v0 = f32x4{0, 0, 0, 0}; v1 = f32x4{0, 0, 0, 0}; }
     f32x4 o;
-    o[0] = h ? v0[1] : v0[0];
-    o[1] = h ? v0[3] : v0[2];
-    o[2] = h ? v1[1] : v1[0];
-    o[3] = h ? v1[3] : v1[2];
+    if (Dreal != D) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = 8 * g + 2 * q + h;
+        o[q] = (real && c < Dreal) ? srow[c] : 0.0f;
+      }
+    } else {
+      f32x4 v0 = row[2 * g], v1 = row[2 * g + 1];
+      if (!real) { v0 = f32x4{0, 0, 0, 0}; v1 = f32x4{0, 0, 0, 0}; }
+      o[0] = h ? v0[1] : v0[0];
+      o[1] = h ? v0[3] : v0[2];
+      o[2] = h ? v1[1] : v1[0];
+      o[3] = h ? v1[3] : v1[2];
+    }
     dst[g * 64] = o;
 #pragma unroll
     for (int q = 0; q < 4; ++q) p = __builtin_fmaf(o[q], o[q], p);
@@ -1675,11 +1726,11 @@ __global__ __launch_bounds__(256) void vq_gather_st_kernel(const float* __restri
   }
 }
 
-template <int D, int CT, bool NCHW, bool TEMP, bool PAIRWISE>
+template <int D, int CT, bool NCHW, bool TEMP, bool PAIRWISE, bool PAD = false>
 int launch_mfma(const SearchArgs& a, hipStream_t s) {
   constexpr int lds_bytes = (int)(2 * vq_stage_floats(D) * 4 + 256);
-  auto kern = vq_search_mfma_kernel<D, CT, NCHW, TEMP, PAIRWISE>;
-  const int arc = vq_lds_ready<vq_search_mfma_kernel<D, CT, NCHW, TEMP, PAIRWISE>, lds_bytes>();
+  auto kern = vq_search_mfma_kernel<D, CT, NCHW, TEMP, PAIRWISE, PAD>;
+  const int arc = vq_lds_ready<vq_search_mfma_kernel<D, CT, NCHW, TEMP, PAIRWISE, PAD>, lds_bytes>();
   if (arc != VQ_OK) return arc;
   const int64_t blocks = (a.N + VQ_WG_ROWS - 1) / VQ_WG_ROWS;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)(a.ksplit > 1 ? a.ksplit : 1)), dim3(512 / CT), lds_bytes, s, a);
@@ -1696,6 +1747,12 @@ template <> struct TileChoice<256> { static constexpr int CT = VQ_CT_256; };
 template <int D>
 int dispatch_mfma(const SearchArgs& a, bool nchw, bool temp, bool pairwise, hipStream_t s) {
   constexpr int CT = TileChoice<D>::CT;
+  if (a.Dreal != D) {
+    // fewer channels in memory than the kernel runs at: the zero-padded form (not for the pairwise sweep)
+    if (pairwise || a.Dreal > D || a.Dreal <= 0) return VQ_ERR_UNSUPPORTED;
+    if (nchw) return temp ? launch_mfma<D, 1, true, true, false, true>(a, s) : launch_mfma<D, 1, true, false, false, true>(a, s);
+    return temp ? launch_mfma<D, 1, false, true, false, true>(a, s) : launch_mfma<D, 1, false, false, false, true>(a, s);
+  }
   if (pairwise) return launch_mfma<D, CT, false, false, true>(a, s);
   if (nchw) return temp ? launch_mfma<D, CT, true, true, false>(a, s) : launch_mfma<D, CT, true, false, false>(a, s);
   return temp ? launch_mfma<D, CT, false, true, false>(a, s) : launch_mfma<D, CT, false, false, false>(a, s);
@@ -1851,8 +1908,8 @@ size_t vq_search_split_bytes(int64_t N, int K) {
 }
 
 size_t vq_image_bytes(int K, int D) {
-  if (K <= 0 || D <= 0 || !vq_fast_dim(D)) return 256;
-  return (size_t)(vq_kpad(K) / VQ_STAGE_CODES) * vq_stage_floats(D) * 4;
+  if (K <= 0 || D <= 0 || vq_pad_dim(D) == 0) return 256;
+  return (size_t)(vq_kpad(K) / VQ_STAGE_CODES) * vq_stage_floats(vq_pad_dim(D)) * 4;
 }
 size_t vq_norms_bytes(int K) { return K > 0 ? (size_t)vq_kpad(K) * 4 : 256; }
 int64_t vq_search_blocks(int64_t N) { return N > 0 ? (N + VQ_WG_ROWS - 1) / VQ_WG_ROWS : 0; }
@@ -1884,15 +1941,17 @@ int vq_codebook_prep(const float* E, int K, int D, float* image, float* e2, int3
   if (D > 4096) return VQ_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   const int Kpad = vq_kpad(K);
-  if (vq_fast_dim(D) && image != nullptr) {
-    if (!aligned16(E) || !aligned16(image)) return VQ_ERR_INVALID_ARG;
+  if (vq_pad_dim(D) != 0 && image != nullptr) {
+    // (a row of E is read 16 bytes at a time only when its length is one of the kernels' own channel counts)
+    if ((vq_fast_dim(D) && !aligned16(E)) || !aligned16(image)) return VQ_ERR_INVALID_ARG;
     const int tiles = Kpad / 32;
-    switch (D) {
-      case 16: hipLaunchKernelGGL(vq_prep_image_kernel<16>, dim3(tiles), dim3(64), 0, s, E, K, image, e2, control); break;
-      case 32: hipLaunchKernelGGL(vq_prep_image_kernel<32>, dim3(tiles), dim3(64), 0, s, E, K, image, e2, control); break;
-      case 64: hipLaunchKernelGGL(vq_prep_image_kernel<64>, dim3(tiles), dim3(64), 0, s, E, K, image, e2, control); break;
-      case 128: hipLaunchKernelGGL(vq_prep_image_kernel<128>, dim3(tiles), dim3(64), 0, s, E, K, image, e2, control); break;
-      default: hipLaunchKernelGGL(vq_prep_image_kernel<256>, dim3(tiles), dim3(64), 0, s, E, K, image, e2, control); break;
+    const float* nobias = nullptr;
+    switch (vq_pad_dim(D)) {
+      case 16: hipLaunchKernelGGL(vq_prep_image_kernel<16>, dim3(tiles), dim3(64), 0, s, E, K, image, e2, control, nobias, 0, D); break;
+      case 32: hipLaunchKernelGGL(vq_prep_image_kernel<32>, dim3(tiles), dim3(64), 0, s, E, K, image, e2, control, nobias, 0, D); break;
+      case 64: hipLaunchKernelGGL(vq_prep_image_kernel<64>, dim3(tiles), dim3(64), 0, s, E, K, image, e2, control, nobias, 0, D); break;
+      case 128: hipLaunchKernelGGL(vq_prep_image_kernel<128>, dim3(tiles), dim3(64), 0, s, E, K, image, e2, control, nobias, 0, D); break;
+      default: hipLaunchKernelGGL(vq_prep_image_kernel<256>, dim3(tiles), dim3(64), 0, s, E, K, image, e2, control, nobias, 0, D); break;
     }
   } else {
     hipLaunchKernelGGL(vq_prep_norms_kernel, dim3((2 * Kpad + 255) / 256), dim3(256), 0, s, E, K, Kpad, D, e2, control);
@@ -1910,7 +1969,7 @@ static int search_common(const float* z, int layout, int64_t N, int D, int64_t H
   if (D > 4096 || N >= (int64_t)1 << 31 || (int64_t)K + code_base >= (int64_t)1 << 31) return VQ_ERR_UNSUPPORTED;
   const bool nchw = layout == VQ_LAYOUT_NCHW;
   SearchArgs a{};
-  a.z = z; a.E = E; a.image = image; a.e2 = e2; a.N = N; a.HW = nchw ? HW : 1; a.K = K;
+  a.z = z; a.E = E; a.image = image; a.e2 = e2; a.N = N; a.HW = nchw ? HW : 1; a.K = K; a.Dreal = D;
   a.nstages = vq_kpad(K) / VQ_STAGE_CODES; a.T = temperature; a.code_base = code_base;
   a.idx64 = idx64; a.idx32 = idx32; a.dmin = dmin; a.q_out = q_out; a.loss_partial = loss_partial;
   a.nf_rows = nf_rows; a.control = control;
@@ -1920,8 +1979,12 @@ static int search_common(const float* z, int layout, int64_t N, int D, int64_t H
   // T > 0 and finite keeps the MFMA path (division by it is monotone); anything else is
   // evaluated literally by the exact kernel.
   const bool t_regular = temperature > 0.0f && temperature < __builtin_inff();
-  const bool fast = !force_exact && vq_fast_dim(D) && image != nullptr && t_regular && aligned16(z) &&
-                    aligned16(E) && aligned16(image) && idx32 != nullptr && nf_rows != nullptr && control != nullptr;
+  // the matrix-core kernels: any D up to 256 (channel counts other than 16 / 32 / 64 / 128 / 256 run zero-padded
+  // to the next of those and read z and E element by element, so only the kernels' own counts need alignment)
+  const int Dp = vq_pad_dim(D);
+  const bool padded = Dp != D;
+  const bool fast = !force_exact && Dp != 0 && image != nullptr && t_regular && (padded || (aligned16(z) && aligned16(E))) &&
+                    aligned16(image) && idx32 != nullptr && nf_rows != nullptr && control != nullptr;
   if (fast) {
     const SplitPlan sp = split_plan(N, K);
     a.ksplit = 1;
@@ -1935,7 +1998,7 @@ static int search_common(const float* z, int layout, int64_t N, int D, int64_t H
       a.part_i = reinterpret_cast<int32_t*>(a.part_d + (size_t)sp.ksplit * N);
       a.q_out = nullptr;
       a.loss_partial = nullptr;
-      rc = run_mfma(a, D, nchw, temperature != 1.0f, false, s);
+      rc = run_mfma(a, Dp, nchw, temperature != 1.0f, false, s);
       if (rc != VQ_OK) return rc;
       hipLaunchKernelGGL(vq_split_merge_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, a.part_d, a.part_i,
                          sp.ksplit, N, idx64, idx32, dmin);
@@ -1947,12 +2010,12 @@ static int search_common(const float* z, int layout, int64_t N, int D, int64_t H
       a.q_out = q_out;
       a.loss_partial = loss_partial;
       a.ksplit = 1;
-    } else if (cyc_eligible(N, K, D, nchw, a.HW)) {
+    } else if (!padded && cyc_eligible(N, K, D, nchw, a.HW)) {
       // short sweep, large batch: the persistent kernel (same winners, distances and outputs)
       rc = run_cyclic(a, D, nchw, temperature != 1.0f, s);
       if (rc != VQ_OK) return rc;
     } else {
-      rc = run_mfma(a, D, nchw, temperature != 1.0f, false, s);
+      rc = run_mfma(a, Dp, nchw, temperature != 1.0f, false, s);
       if (rc != VQ_OK) return rc;
     }
     // rows flagged by the MFMA kernel (normally none: the kernel then exits at once)
@@ -2010,7 +2073,7 @@ int vq_search_filtered(const float* z, int layout, int64_t N, int D, int64_t HW,
     VQ_CHECK_HIP(hipGetLastError());
   }
   SearchArgs a{};
-  a.z = z; a.E = E; a.image = image; a.e2 = e2; a.N = N; a.HW = nchw ? HW : 1; a.K = K;
+  a.z = z; a.E = E; a.image = image; a.e2 = e2; a.N = N; a.HW = nchw ? HW : 1; a.K = K; a.Dreal = D;
   a.nstages = vq_kpad(K) / VQ_STAGE_CODES; a.T = temperature; a.code_base = code_base;
   a.idx64 = idx64; a.idx32 = idx32; a.dmin = dmin; a.q_out = q_out;
   a.nf_rows = nf_rows; a.control = control; a.ksplit = 1; a.stages_per_split = a.nstages;
@@ -2098,7 +2161,7 @@ int vq_pairwise_search_launch(const float* E, const float* image, const float* e
   // internal helper of vq_pairwise_stats / vq_pairwise_rows (vq_stats.hip); not part of the public header.
   // Rows [row_base, row_base + n_rows) of the codebook play the latents, all K rows the codes.
   SearchArgs a{};
-  a.z = E + (size_t)row_base * D; a.E = E; a.image = image; a.e2 = e2; a.N = n_rows; a.HW = 1; a.K = K;
+  a.z = E + (size_t)row_base * D; a.E = E; a.image = image; a.e2 = e2; a.N = n_rows; a.HW = 1; a.K = K; a.Dreal = D;
   a.nstages = vq_kpad(K) / VQ_STAGE_CODES; a.T = 1.0f; a.code_base = 0;
   a.idx64 = nn_idx; a.idx32 = idx32; a.dmin = nn_dist; a.q_out = nullptr; a.loss_partial = nullptr;
   a.nf_rows = nf_rows; a.control = control; a.pw_sum = sum_partial; a.pw_minmax = mm_partial;
