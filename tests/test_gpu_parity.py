@@ -417,3 +417,32 @@ def test_zero_padded_channel_counts_run_on_the_matrix_cores(K, D, shape, T, dev,
     lib = load()
     dp = next(p for p in (16, 32, 64, 128, 256) if p >= D)
     assert lib.vq_image_bytes(K, D) == lib.vq_image_bytes(K, dp) > 256
+
+
+def test_temperature_fuzz_against_the_exact_kernel(dev, ops):
+    """Random temperatures in (0, 100] (vqvae/ema_vector_quantizer.py:49-50 divides every distance by T), on
+    random codebooks and on codebooks of near-duplicates, where rounding the quotient creates ties that the
+    lower index must win: the matrix-core kernels against the exact kernel and the oracle, indices and
+    quotients bit for bit."""
+    rng = np.random.default_rng(1801)
+    for trial in range(24):
+        K, D = [(8192, 64), (1000, 32), (512, 256), (4096, 128)][trial % 4]
+        T = float(np.float32(10.0 ** rng.uniform(-3, 2)))
+        z = gauss(1810 + trial, (4, D, 16, 16))
+        if trial % 3 == 0:
+            # clusters of codes a few ulps apart: their quotients collide
+            centers = gauss(1850 + trial, ((K + 15) // 16, D))
+            E = np.repeat(centers, 16, axis=0)[:K] * (1 + rng.integers(-3, 4, (K, 1)).astype(np.float32) * np.float32(2 ** -23))
+            E = np.ascontiguousarray(E[:K].astype(np.float32))
+        else:
+            E = gauss(1850 + trial, (K, D)) * np.float32(10.0 ** rng.uniform(-2, 2))
+        ws = ops.Workspace(dev)
+        zt, Et = _t(z, dev), _t(E, dev)
+        fast = ops.search(zt, Et, ws, temperature=T, want_quantized=False, want_dmin=True)
+        i_f, d_f = fast["indices"].clone(), fast["dmin"].clone()
+        exact = ops.search(zt, Et, ws, temperature=T, want_quantized=False, want_dmin=True, exact=True)
+        torch.cuda.synchronize()
+        assert torch.equal(i_f, exact["indices"]), (trial, K, D, T)
+        assert torch.equal(d_f.view(torch.int32), exact["dmin"].view(torch.int32)), (trial, K, D, T)
+    o_idx, o_d = vo.search(z, E, T)          # and the last trial against the oracle
+    assert np.array_equal(i_f.cpu().numpy(), o_idx) and np.array_equal(_bits(d_f.cpu().numpy()), _bits(o_d))
