@@ -227,6 +227,27 @@ int vq_ema_codebook_update(const float* slabs, int nslab, int K, int D, float de
                            const float* cluster_size, float* ema_w, float* E, void* stream);
 
 /*
+ * The same three K-sized steps with fewer launches, for steps so short that launches are what they
+ * cost (a 4096-vector batch is ten launches of 5-12 us of which the arithmetic is a fraction):
+ *   vq_step_finish             = vq_step_scalars + vq_ema_cluster_update in one single-workgroup kernel
+ *                                (usage = cluster_size = NULL: the scalars only, as in eval mode);
+ *   vq_ema_codebook_update_end = vq_ema_codebook_update.
+ * Same arithmetic in the same order as the separate entry points (ref: vqvae/ema_vector_quantizer.py:67-89,
+ * :92, :105-106).  Whichever of the two runs last in a step may also do the step's housekeeping, so that
+ * the next step needs no vq_control_reset and no zeroing of its histogram: cleanup_control (may be NULL):
+ * the 16 control words -- words 0..7 are copied to words 8..15, where the step's counters stay readable,
+ * then zeroed; cleanup_counts (may be NULL): K histogram bins to zero, i.e. the buffer the NEXT step will
+ * count into with accumulate = 1 (alternate two buffers: this step's counts stay readable).
+ */
+int vq_step_finish(const float* loss_partial, int64_t n_partial, int64_t N_total, int D, float beta,
+                   const uint32_t* counts, int K, float decay, float one_minus_decay, float eps, float k_eps,
+                   float* usage, float* cluster_size, float* loss_out, float* perplexity_out,
+                   int32_t* cleanup_control, uint32_t* cleanup_counts, void* stream);
+int vq_ema_codebook_update_end(const float* slabs, int nslab, int K, int D, float decay, float one_minus_decay,
+                               const float* cluster_size, float* ema_w, float* E, int32_t* cleanup_control,
+                               uint32_t* cleanup_counts, void* stream);
+
+/*
  * Backward of the forward's differentiable part.  ref: autograd of
  * vqvae/ema_vector_quantizer.py:92 and :95:
  *   grad_z = grad_q + grad_loss * coef * (z - q_st),  coef = 2*beta/(N*D)
@@ -365,6 +386,38 @@ int vq_pairwise_rows(const float* E, const float* image, const float* e2, int K,
 #define VQ_PAIRWISE_STATIC_MAX_K 65536
 int vq_pairwise_stats_static(const float* E, const float* image, const float* e2, int K, int D, float* nn_dist,
                              int64_t* nn_idx, double* out, int32_t* control, void* stream);
+
+/*
+ * One whole forward of the quantizer in ONE call: vq_codebook_prep -> vq_search -> vq_code_histogram ->
+ * (training) vq_ema_scatter[_sorted] -> vq_step_finish -> (training) vq_ema_codebook_update_end, enqueued
+ * back to back on `stream`.  ref: vqvae/ema_vector_quantizer.py:33-108, the forward as a whole.  For a host
+ * whose per-call overhead matters (a Python binding pays microseconds per call; a 4096-vector step is
+ * a dozen launches of a few microseconds each).  Nothing here that the separate entry points do not do;
+ * buffers and their sizes are those of the separate entry points:
+ *   image, e2, control         vq_image_bytes, vq_norms_bytes, vq_control_bytes
+ *   idx32, nf_rows             N int32 each
+ *   loss_partial               vq_loss_partial_bytes(N)
+ *   split_ws                   vq_search_split_bytes(N, K) bytes, or NULL
+ *   counts, counts_next        K uint32 each: the two alternating histogram buffers (see vq_step_finish)
+ *   slabs, nslab               training: vq_scatter_slabs_for(...) * K * D floats; with sort_work != NULL
+ *                              (row-major z, vq_scatter_sorted_supported) one slab and the counting-sort path
+ *   sort_work                  vq_scatter_sorted_work_bytes(N, K, D) bytes, or NULL
+ * control_clean != 0: the previous call on these buffers finished and nothing else has touched `control` or
+ * `counts` since, so they are zero already; otherwise they are zeroed first (two memsets).
+ * Outputs: idx64 [N], q_out (layout of z), loss_out, perplexity_out (device scalars), dmin [N] or NULL;
+ * training != 0 also updates usage, cluster_size, ema_w and E in place.
+ */
+typedef struct vq_step_args {
+  const float* z; int layout; int64_t N; int D; int64_t HW;
+  float* E; float* ema_w; float* cluster_size; float* usage; int K;
+  float beta, decay, one_minus_decay, eps, k_eps, temperature;
+  int training;
+  int64_t* idx64; float* q_out; float* loss_out; float* perplexity_out; float* dmin;
+  float* image; float* e2; int32_t* control; int32_t* idx32; int32_t* nf_rows; float* loss_partial; void* split_ws;
+  uint32_t* counts; uint32_t* counts_next; float* slabs; int nslab; void* sort_work;
+  int control_clean;
+} vq_step_args;
+int vq_quantize_step(const vq_step_args* args, void* stream);
 
 /*
  * Codebook-row-sharded search support: pack (distance, index) into one int64 whose

@@ -60,6 +60,11 @@ SIGNATURES = {
                                       c_void_p, c_void_p]),
     "vq_ema_codebook_update": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p,
                                        c_void_p]),
+    "vq_step_finish": (c_int, [c_void_p, c_int64, c_int64, c_int, c_float, c_void_p, c_int, c_float, c_float, c_float,
+                               c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vq_ema_codebook_update_end": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_void_p]),
+    "vq_quantize_step": (c_int, [c_void_p, c_void_p]),
     "vq_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p]),
     "vq_gather_project": (c_int, [c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                   c_void_p, c_void_p, c_void_p]),
@@ -88,6 +93,22 @@ SIGNATURES = {
     "vq_packed_min": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "vq_unpack_dist_index": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
+
+
+class StepArgs(ctypes.Structure):
+    """vq_step_args of include/vq_hip.h, field for field."""
+    _fields_ = [("z", c_void_p), ("layout", c_int), ("N", c_int64), ("D", c_int), ("HW", c_int64),
+                ("E", c_void_p), ("ema_w", c_void_p), ("cluster_size", c_void_p), ("usage", c_void_p), ("K", c_int),
+                ("beta", c_float), ("decay", c_float), ("one_minus_decay", c_float), ("eps", c_float),
+                ("k_eps", c_float), ("temperature", c_float),
+                ("training", c_int),
+                ("idx64", c_void_p), ("q_out", c_void_p), ("loss_out", c_void_p), ("perplexity_out", c_void_p),
+                ("dmin", c_void_p),
+                ("image", c_void_p), ("e2", c_void_p), ("control", c_void_p), ("idx32", c_void_p), ("nf_rows", c_void_p),
+                ("loss_partial", c_void_p), ("split_ws", c_void_p),
+                ("counts", c_void_p), ("counts_next", c_void_p), ("slabs", c_void_p), ("nslab", c_int),
+                ("sort_work", c_void_p),
+                ("control_clean", c_int)]
 
 
 class VQLibraryError(RuntimeError):

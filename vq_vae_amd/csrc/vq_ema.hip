@@ -425,6 +425,79 @@ __global__ __launch_bounds__(1024) void vq_cluster_update_kernel(const uint32_t*
   for (int k = t; k < K; k += 1024) cs[k] = (cs[k] + eps) / denom * n;  // ref :76-80, stored back
 }
 
+// End-of-step housekeeping, done by whichever kernel runs last in a step so that the next step needs no
+// memsets: the control words are copied to words 8..15 (where the host can still read the step's counters)
+// and zeroed, and the histogram bins of the NEXT step (the other of two alternating buffers) are zeroed.
+__device__ __forceinline__ void vq_step_cleanup(int32_t* control, uint32_t* counts_next, int K, int64_t tid,
+                                                int64_t nthreads) {
+  if (control != nullptr && tid < 8) {
+    const int32_t v = control[tid];
+    control[8 + tid] = v;
+    control[tid] = 0;
+  }
+  if (counts_next != nullptr)
+    for (int64_t k = tid; k < K; k += nthreads) counts_next[k] = 0u;
+}
+
+// vq_step_scalars and vq_ema_cluster_update in one launch (both are single-workgroup kernels over K-sized
+// vectors; the arithmetic and its order are those of the two kernels).  usage == nullptr: scalars only.
+__global__ __launch_bounds__(1024) void vq_step_finish_kernel(const float* __restrict__ loss_partial, int64_t n_partial,
+                                                              int64_t N_total, int D, float beta,
+                                                              const uint32_t* __restrict__ counts, int K, float decay,
+                                                              float omd, float eps, float k_eps, float* __restrict__ usage,
+                                                              float* __restrict__ cs, float* loss_out,
+                                                              float* perplexity_out, int32_t* cleanup_control,
+                                                              uint32_t* cleanup_counts) {
+  __shared__ double sh[1024];
+  const int t = threadIdx.x;
+  if (loss_partial && loss_out) {
+    double s = 0.0;
+    for (int64_t i = t; i < n_partial; i += 1024) s += (double)loss_partial[i];
+    const double tot = block_sum_1024(s, sh);
+    if (t == 0) *loss_out = beta * (float)(tot / ((double)N_total * (double)D));   // ref :92
+  }
+  if (counts && perplexity_out) {
+    double s = 0.0;
+    const float nf = (float)N_total;
+    for (int k = t; k < K; k += 1024) {
+      const float p = (float)counts[k] / nf;           // ref :105
+      s += (double)(p * logf(p + 1e-10f));             // ref :106
+    }
+    const double tot = block_sum_1024(s, sh);
+    if (t == 0) *perplexity_out = expf(-(float)tot);
+  }
+  if (usage != nullptr) {
+    double s = 0.0;
+    for (int k = t; k < K; k += 1024) {
+      const float c = (float)counts[k];
+      usage[k] = usage[k] + c;                       // ref :67
+      const float v = cs[k] * decay + omd * c;       // ref :71-72
+      cs[k] = v;
+      s += (double)v;
+    }
+    const float n = (float)block_sum_1024(s, sh);    // ref :75
+    const float denom = n + k_eps;
+    for (int k = t; k < K; k += 1024) cs[k] = (cs[k] + eps) / denom * n;  // ref :76-80, stored back
+  }
+  vq_step_cleanup(cleanup_control, cleanup_counts, K, t, 1024);
+}
+
+__global__ __launch_bounds__(256) void vq_codebook_update_end_kernel(const float* __restrict__ slabs, int nslab, int K,
+                                                                     int D, float decay, float omd,
+                                                                     const float* __restrict__ cs,
+                                                                     float* __restrict__ ema_w, float* __restrict__ E,
+                                                                     int32_t* cleanup_control, uint32_t* cleanup_counts) {
+  const int64_t KD = (int64_t)K * D;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  vq_step_cleanup(cleanup_control, cleanup_counts, K, i, (int64_t)gridDim.x * 256);
+  if (i >= KD) return;
+  float dw = slabs[i];
+  for (int t = 1; t < nslab; ++t) dw += slabs[(size_t)t * KD + i];
+  const float w = ema_w[i] * decay + omd * dw;     // ref :85
+  ema_w[i] = w;
+  E[i] = w / cs[i / D];                            // ref :89
+}
+
 __global__ __launch_bounds__(256) void vq_codebook_update_kernel(const float* __restrict__ slabs, int nslab, int K, int D,
                                                                  float decay, float omd, const float* __restrict__ cs,
                                                                  float* __restrict__ ema_w, float* __restrict__ E) {
@@ -691,6 +764,71 @@ int vq_ema_codebook_update(const float* slabs, int nslab, int K, int D, float de
   hipLaunchKernelGGL(vq_codebook_update_kernel, dim3((unsigned)((KD + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, slabs, nslab, K, D, decay, one_minus_decay, cluster_size, ema_w, E);
   return vq_hip_status(hipGetLastError());
+}
+
+int vq_step_finish(const float* loss_partial, int64_t n_partial, int64_t N_total, int D, float beta,
+                   const uint32_t* counts, int K, float decay, float one_minus_decay, float eps, float k_eps,
+                   float* usage, float* cluster_size, float* loss_out, float* perplexity_out,
+                   int32_t* cleanup_control, uint32_t* cleanup_counts, void* stream) {
+  if (N_total <= 0 || D <= 0 || K <= 0 || !counts) return VQ_ERR_INVALID_ARG;
+  if ((usage == nullptr) != (cluster_size == nullptr)) return VQ_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(vq_step_finish_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, loss_partial, n_partial,
+                     N_total, D, beta, counts, K, decay, one_minus_decay, eps, k_eps, usage, cluster_size, loss_out,
+                     perplexity_out, cleanup_control, cleanup_counts);
+  return vq_hip_status(hipGetLastError());
+}
+
+int vq_ema_codebook_update_end(const float* slabs, int nslab, int K, int D, float decay, float one_minus_decay,
+                               const float* cluster_size, float* ema_w, float* E, int32_t* cleanup_control,
+                               uint32_t* cleanup_counts, void* stream) {
+  if (!slabs || !cluster_size || !ema_w || !E || nslab <= 0 || K <= 0 || D <= 0) return VQ_ERR_INVALID_ARG;
+  const int64_t KD = (int64_t)K * D;
+  hipLaunchKernelGGL(vq_codebook_update_end_kernel, dim3((unsigned)((KD + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, slabs, nslab, K, D, decay, one_minus_decay, cluster_size, ema_w, E,
+                     cleanup_control, cleanup_counts);
+  return vq_hip_status(hipGetLastError());
+}
+
+int vq_quantize_step(const vq_step_args* p, void* stream) {
+  if (!p || !p->z || !p->E || !p->idx64 || !p->q_out || !p->loss_out || !p->perplexity_out || !p->image || !p->e2 ||
+      !p->control || !p->idx32 || !p->nf_rows || !p->loss_partial || !p->counts || !p->counts_next)
+    return VQ_ERR_INVALID_ARG;
+  if (p->N <= 0 || p->K <= 0 || p->D <= 0) return VQ_ERR_INVALID_ARG;
+  if (p->training && (!p->ema_w || !p->cluster_size || !p->usage || !p->slabs || p->nslab <= 0)) return VQ_ERR_INVALID_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if (!p->control_clean) {
+    rc = vq_control_reset(p->control, stream);
+    if (rc != VQ_OK) return rc;
+    VQ_CHECK_HIP(hipMemsetAsync(p->counts, 0, (size_t)p->K * 4, s));
+  }
+  rc = vq_codebook_prep(p->E, p->K, p->D, p->image, p->e2, p->control, stream);
+  if (rc != VQ_OK) return rc;
+  rc = vq_search(p->z, p->layout, p->N, p->D, p->HW, p->E, p->image, p->e2, p->K, p->temperature, 0, p->idx64, p->idx32,
+                 p->dmin, p->q_out, p->loss_partial, p->nf_rows, p->control, p->split_ws, stream);
+  if (rc != VQ_OK) return rc;
+  rc = vq_code_histogram(p->idx32, 0, p->N, p->K, p->counts, 1, p->control, stream);
+  if (rc != VQ_OK) return rc;
+  const int64_t n_partial = (int64_t)(vq_loss_partial_bytes(p->N) / 4);
+  if (p->training) {
+    int nslab = p->nslab;
+    if (p->sort_work != nullptr) {
+      rc = vq_ema_scatter_sorted(p->z, p->N, p->D, p->idx32, p->K, 0, 1, p->control, p->slabs, p->sort_work, stream);
+      nslab = 1;
+    } else {
+      rc = vq_ema_scatter(p->z, p->layout, p->N, p->D, p->HW, p->idx32, p->K, 0, 1, p->control, p->slabs, nslab, stream);
+    }
+    if (rc != VQ_OK) return rc;
+    rc = vq_step_finish(p->loss_partial, n_partial, p->N, p->D, p->beta, p->counts, p->K, p->decay, p->one_minus_decay,
+                        p->eps, p->k_eps, p->usage, p->cluster_size, p->loss_out, p->perplexity_out, nullptr, nullptr,
+                        stream);
+    if (rc != VQ_OK) return rc;
+    return vq_ema_codebook_update_end(p->slabs, nslab, p->K, p->D, p->decay, p->one_minus_decay, p->cluster_size,
+                                      p->ema_w, p->E, p->control, p->counts_next, stream);
+  }
+  return vq_step_finish(p->loss_partial, n_partial, p->N, p->D, p->beta, p->counts, p->K, p->decay, p->one_minus_decay,
+                        p->eps, p->k_eps, nullptr, nullptr, p->loss_out, p->perplexity_out, p->control, p->counts_next,
+                        stream);
 }
 
 int vq_backward(const float* grad_q, const float* grad_loss, const float* z, const float* q_st, int64_t numel,

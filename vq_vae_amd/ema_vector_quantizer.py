@@ -278,7 +278,9 @@ class EMAVectorQuantizer(nn.Module):
         rows its first and second pass left open."""
         if self._ws is None or "control" not in self._ws._bufs:
             return {"nonfinite_rows": 0, "codebook_not_finite": False, "filter_open_rows": 0, "filter_hard_rows": 0}
-        c = self._ws._bufs["control"][:64].view(torch.int32)[:8].cpu().tolist()
+        # a finished step moves its counters from words 0..7 to words 8..15 and zeroes the former for the next step
+        words = self._ws._bufs["control"][:64].view(torch.int32)
+        c = (words[8:16] if self._ws.clean else words[:8]).cpu().tolist()
         return {"nonfinite_rows": int(c[0]), "codebook_not_finite": bool(c[1]), "filter_open_rows": int(c[4]),
                 "filter_hard_rows": int(c[5])}
 

@@ -61,18 +61,35 @@ def ema_scalars(K: int, decay: float, epsilon: float):
 
 @dataclass
 class Workspace:
-    """Grow-only device buffers reused from call to call (never part of a state_dict)."""
+    """Grow-only device buffers reused from call to call (never part of a state_dict).
+
+    ``clean`` says that the last kernel of the previous ``quantize_step`` on this workspace left the control
+    words and the next step's histogram bins zeroed, so the step needs no memsets; anything else that
+    touches the control block clears it, and the next step then resets explicitly.  ``flip`` selects which
+    of the two alternating histogram buffers the next step counts into."""
     device: torch.device
     _bufs: dict = field(default_factory=dict)
+    clean: bool = False
+    flip: int = 0
+    counts_k: int = 0       # codebook size the alternating histogram buffers were zeroed for
+
+    _views: dict = field(default_factory=dict)
 
     def get(self, name: str, nbytes: int, dtype=torch.uint8) -> torch.Tensor:
         nbytes = max(int(nbytes), 256)
+        key = (name, nbytes, dtype)
+        view = self._views.get(key)        # the same request as last step: no tensor arithmetic at all
+        if view is not None:
+            return view
         buf = self._bufs.get(name)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             self._bufs[name] = buf
+            self._views = {k: v for k, v in self._views.items() if k[0] != name}   # views of the old buffer
         item = torch.empty((), dtype=dtype).element_size()
-        return buf[: nbytes // item * item].view(dtype)
+        view = buf[: nbytes // item * item].view(dtype)
+        self._views[key] = view
+        return view
 
 
 @dataclass
@@ -100,15 +117,18 @@ def _shape_of(z: torch.Tensor, D: int):
     raise RuntimeError(f"expected (B, C, H, W) or (N, D) latents, got {tuple(z.shape)}")
 
 
-def prepare_codebook(E: torch.Tensor, ws: Workspace):
-    """vq_codebook_prep: squared norms + MFMA image of the codebook.  Returns (image, e2, control)."""
+def prepare_codebook(E: torch.Tensor, ws: Workspace, reset: bool = True):
+    """vq_codebook_prep: squared norms + MFMA image of the codebook.  Returns (image, e2, control).
+    ``reset=False`` is for a caller that knows the control words are zero already."""
     lib = _lib.load()
     K, D = E.shape
     image = ws.get("image", lib.vq_image_bytes(K, D), torch.float32)
     e2 = ws.get("e2", lib.vq_norms_bytes(K), torch.float32)
     control = ws.get("control", lib.vq_control_bytes(), torch.int32)
     s = _stream(E.device)
-    check(lib.vq_control_reset(_ptr(control), s), "vq_control_reset")
+    if reset:
+        ws.clean = False
+        check(lib.vq_control_reset(_ptr(control), s), "vq_control_reset")
     check(lib.vq_codebook_prep(_ptr(E), K, D, _ptr(image), _ptr(e2), _ptr(control), s), "vq_codebook_prep")
     return image, e2, control
 
@@ -237,6 +257,7 @@ def histogram(idx: torch.Tensor, K: int, ws: Workspace, out: Optional[torch.Tens
     idx = idx.contiguous().view(-1)
     counts = out if out is not None else torch.empty(K, dtype=torch.int32, device=idx.device)
     control = ws.get("control", lib.vq_control_bytes(), torch.int32)
+    ws.clean = False      # (the bad-index counter in the control block)
     check(lib.vq_code_histogram(_ptr(idx), 1 if idx.dtype == torch.int64 else 0, idx.numel(), K, _ptr(counts),
                                 1 if accumulate else 0, _ptr(control), _stream(idx.device)), "vq_code_histogram")
     return counts
@@ -552,6 +573,9 @@ def quantize_step(z: torch.Tensor, E: torch.Tensor, ema_w, cluster_size, usage, 
         return out
     if z.numel() == 0:
         return _empty_step(z, E, ema_w, cluster_size, usage, decay, epsilon, training, ws, stats_reduce, project)
+    if stats_reduce is None:
+        return _local_step(z, E, ema_w, cluster_size, usage, beta, decay, epsilon, temperature, training, ws,
+                           want_dmin, search_events, filtered, project)
     r = search(z, E, ws, temperature=temperature, want_quantized=project is None, want_dmin=want_dmin,
                events=search_events, filtered=filtered)
     if project is not None:
@@ -560,24 +584,120 @@ def quantize_step(z: torch.Tensor, E: torch.Tensor, ema_w, cluster_size, usage, 
     N = r["N"]
     counts = ws.get("counts", K * 4, torch.int32)[:K]
     histogram(r["idx32"][:N], K, ws, out=counts)
-    loss, perp, _ = step_scalars(r["loss_partial"], r["n_partial"], N, D, beta,
-                                 counts if stats_reduce is None else None, K, z.device)
-    if stats_reduce is None:
-        if training:
-            slabs, _ = embed_sums(_f32c(z, "latents"), r["idx32"], K, ws, zmax_valid=r["zmax_valid"])
-            ema_update(counts, slabs, usage, cluster_size, ema_w, E, decay, epsilon)
-    else:
-        dw = None
-        if training:
-            slabs, _ = embed_sums(_f32c(z, "latents"), r["idx32"], K, ws, zmax_valid=r["zmax_valid"])
-            dw = reduce_slabs(slabs, out=ws.get("dw", K * D * 4, torch.float32)[: K * D].view(K, D))
-        counts64, dw, n_total = stats_reduce(counts, dw, N)
-        # perplexity and the EMA update come from the reduced statistics, so every rank computes
-        # bit-identical values and the replicas stay in step without a broadcast
-        _, perp, _ = step_scalars(None, 0, n_total, D, beta, counts64.to(torch.int32), K, z.device)
-        if training:
-            ema_update(None, dw, usage, cluster_size, ema_w, E, decay, epsilon, counts64=counts64)
+    loss, perp, _ = step_scalars(r["loss_partial"], r["n_partial"], N, D, beta, None, K, z.device)
+    dw = None
+    if training:
+        slabs, _ = embed_sums(_f32c(z, "latents"), r["idx32"], K, ws, zmax_valid=r["zmax_valid"])
+        dw = reduce_slabs(slabs, out=ws.get("dw", K * D * 4, torch.float32)[: K * D].view(K, D))
+    counts64, dw, n_total = stats_reduce(counts, dw, N)
+    # perplexity and the EMA update come from the reduced statistics, so every rank computes
+    # bit-identical values and the replicas stay in step without a broadcast
+    _, perp, _ = step_scalars(None, 0, n_total, D, beta, counts64.to(torch.int32), K, z.device)
+    if training:
+        ema_update(None, dw, usage, cluster_size, ema_w, E, decay, epsilon, counts64=counts64)
     return StepResult(r["quantized"], loss, perp, r["indices"], counts, r["dmin"])
+
+
+def _local_step(z, E, ema_w, cluster_size, usage, beta, decay, epsilon, temperature, training, ws, want_dmin,
+                search_events, filtered, project) -> StepResult:
+    """The step on one device, in as few launches as it takes: codebook image, search (+ the exact kernel for
+    flagged rows), histogram into pre-zeroed bins, EMA sums, one kernel for loss + perplexity + cluster sizes, one
+    for the codebook.  The last kernel zeroes the control words and the other histogram buffer for the next
+    step, so a step in steady state issues no memsets (for a 4096-vector batch the launches are the cost)."""
+    lib = _lib.load()
+    K, D = E.shape
+    dev = z.device
+    s = _stream(dev)
+    control = ws.get("control", lib.vq_control_bytes(), torch.int32)
+    both = ws.get("counts2", 2 * K * 4, torch.int32)[: 2 * K].view(2, K)
+    if not filtered and project is None and search_events is None:
+        return _single_call_step(lib, z, E, ema_w, cluster_size, usage, beta, decay, epsilon, temperature, training, ws,
+                                 want_dmin, control, both, s)
+    if not ws.clean or ws.counts_k != K:
+        check(lib.vq_control_reset(_ptr(control), s), "vq_control_reset")
+        both.zero_()
+        ws.counts_k = K
+    ws.clean = False                       # until the last kernel of this step has been issued
+    counts, counts_next = both[ws.flip], both[1 - ws.flip]
+    prepared = prepare_codebook(E, ws, reset=False)
+    r = search(z, E, ws, temperature=temperature, want_quantized=project is None, want_dmin=want_dmin,
+               events=search_events, filtered=filtered, prepared=prepared)
+    if project is not None:
+        # the codebook is still the one the search saw: the EMA update comes last
+        r["quantized"], r["loss_partial"], r["n_partial"] = gather_project(z, E, r["indices"], project, ws)
+    N = r["N"]
+    check(lib.vq_code_histogram(_ptr(r["idx32"]), 0, N, K, _ptr(counts), 1, _ptr(control), s), "vq_code_histogram")
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    perp = torch.empty((), dtype=torch.float32, device=dev)
+    d, omd, eps, keps = ema_scalars(K, decay, epsilon)
+    if training:
+        slabs, _ = embed_sums(_f32c(z, "latents"), r["idx32"], K, ws, zmax_valid=r["zmax_valid"])
+        if slabs.dim() == 2:
+            slabs = slabs.unsqueeze(0)
+        check(lib.vq_step_finish(_ptr(r["loss_partial"]), r["n_partial"], N, D, float(np.float32(beta)), _ptr(counts), K,
+                                 d, omd, eps, keps, _ptr(usage), _ptr(cluster_size), _ptr(loss), _ptr(perp), None, None,
+                                 s), "vq_step_finish")
+        check(lib.vq_ema_codebook_update_end(_ptr(slabs), slabs.shape[0], K, D, d, omd, _ptr(cluster_size), _ptr(ema_w),
+                                             _ptr(E), _ptr(control), _ptr(counts_next), s), "vq_ema_codebook_update_end")
+    else:
+        check(lib.vq_step_finish(_ptr(r["loss_partial"]), r["n_partial"], N, D, float(np.float32(beta)), _ptr(counts), K,
+                                 d, omd, eps, keps, None, None, _ptr(loss), _ptr(perp), _ptr(control), _ptr(counts_next),
+                                 s), "vq_step_finish")
+    ws.clean = True
+    ws.flip = 1 - ws.flip
+    return StepResult(r["quantized"], loss, perp, r["indices"], counts, r["dmin"])
+
+
+def _single_call_step(lib, z, E, ema_w, cluster_size, usage, beta, decay, epsilon, temperature, training, ws, want_dmin,
+                      control, both, s) -> StepResult:
+    """The same step through vq_quantize_step: one call into the library, which enqueues the kernels back to
+    back (the Python side of a call costs as much as a small kernel runs)."""
+    z = _f32c(z, "latents")
+    E = _f32c(E, "codebook")
+    K, D = E.shape
+    dev = z.device
+    layout, N, HW = _shape_of(z, D)
+    a = ws._views.get("step_args")
+    if a is None:
+        a = ws._views["step_args"] = _lib.StepArgs()
+    idx64 = torch.empty(N, dtype=torch.int64, device=dev)
+    q = torch.empty_like(z)
+    scal = torch.empty(2, dtype=torch.float32, device=dev)
+    dmin = torch.empty(N, dtype=torch.float32, device=dev) if want_dmin else None
+    idx32 = ws.get("idx32", N * 4, torch.int32)
+    split_bytes = lib.vq_search_split_bytes(N, K)
+    d, omd, eps, keps = ema_scalars(K, decay, epsilon)
+    a.z, a.layout, a.N, a.D, a.HW = z.data_ptr(), layout, N, D, HW
+    a.E, a.K = E.data_ptr(), K
+    a.beta, a.decay, a.one_minus_decay, a.eps, a.k_eps = float(np.float32(beta)), d, omd, eps, keps
+    a.temperature, a.training = float(temperature), 1 if training else 0
+    a.idx64, a.q_out, a.loss_out, a.perplexity_out = idx64.data_ptr(), q.data_ptr(), scal.data_ptr(), scal.data_ptr() + 4
+    a.dmin = dmin.data_ptr() if dmin is not None else None
+    a.image = ws.get("image", lib.vq_image_bytes(K, D), torch.float32).data_ptr()
+    a.e2 = ws.get("e2", lib.vq_norms_bytes(K), torch.float32).data_ptr()
+    a.control, a.idx32 = control.data_ptr(), idx32.data_ptr()
+    a.nf_rows = ws.get("nf_rows", N * 4, torch.int32).data_ptr()
+    a.loss_partial = ws.get("loss_partial", lib.vq_loss_partial_bytes(N), torch.float32).data_ptr()
+    a.split_ws = ws.get("split", split_bytes).data_ptr() if split_bytes else None
+    clean = ws.clean and ws.counts_k == K      # otherwise the library zeroes control and this step's bins first
+    ws.counts_k = K
+    counts, counts_next = both[ws.flip], both[1 - ws.flip]
+    a.counts, a.counts_next = counts.data_ptr(), counts_next.data_ptr()
+    a.sort_work, a.slabs, a.nslab = None, None, 0
+    if training:
+        a.ema_w, a.cluster_size, a.usage = ema_w.data_ptr(), cluster_size.data_ptr(), usage.data_ptr()
+        if (layout == LAYOUT_ND or HW == 1) and z.data_ptr() % 16 == 0 and lib.vq_scatter_sorted_supported(K, D):
+            a.nslab = 1
+            a.sort_work = ws.get("sort_work", lib.vq_scatter_sorted_work_bytes(N, K, D)).data_ptr()
+        else:
+            a.nslab = lib.vq_scatter_slabs_for(N, K, D, layout, HW)
+        a.slabs = ws.get("slabs", a.nslab * K * D * 4, torch.float32).data_ptr()
+    a.control_clean = 1 if clean else 0
+    ws.clean = False
+    check(lib.vq_quantize_step(ctypes.byref(a), s), "vq_quantize_step")
+    ws.clean = True
+    ws.flip = 1 - ws.flip
+    return StepResult(q, scal[0], scal[1], idx64, counts, dmin)
 
 
 def _empty_step(z, E, ema_w, cluster_size, usage, decay, epsilon, training, ws, stats_reduce, project) -> StepResult:
