@@ -388,6 +388,30 @@ int vq_pairwise_stats_static(const float* E, const float* image, const float* e2
                              int64_t* nn_idx, double* out, int32_t* control, void* stream);
 
 /*
+ * Data-parallel training (one process per GPU; the reference has no multi-device code on this path, the
+ * exchange sits between the statistics of vqvae/ema_vector_quantizer.py:65/:84 and the update of :71-89):
+ * every rank packs its EMA statistics into one fp32 buffer, the ranks SUM-all-reduce it (RCCL), and every
+ * rank finishes the step from the reduced buffer, so all replicas apply the same update.
+ *   buf = [dw (K*D, only if slabs != NULL) | counts mod 4096 (K) | counts div 4096 (K) | rows mod 4096 | rows div 4096]
+ * vq_packed_stats_floats(K, D, with_sums) floats.  The split halves of the counts and of the row count add
+ * exactly in fp32 for up to 4096 ranks of fewer than 2^24 rows each (VQ_ERR_UNSUPPORTED beyond that).
+ * vq_pack_stats: slabs as written by vq_ema_scatter (summed in slab order, as vq_reduce_slabs) or NULL in
+ * eval mode.  vq_step_finish_reduced: vq_step_finish with the counts and the global row count taken from
+ * reduced_tail = buf + (K*D or 0); the loss stays the mean over the N_local rows of this rank (as under
+ * DistributedDataParallel), perplexity and cluster sizes come from the global counts; counts64_out (K) and
+ * n_total_out (1) receive the reduced counts and row count if not NULL.  Then
+ * vq_ema_codebook_update_end(buf, 1, ...) applies the reduced sums.
+ */
+size_t vq_packed_stats_floats(int K, int D, int with_sums);
+int vq_pack_stats(const float* slabs, int nslab, int K, int D, const uint32_t* counts, int64_t n_local, float* buf,
+                  void* stream);
+int vq_step_finish_reduced(const float* loss_partial, int64_t n_partial, int64_t N_local, int D, float beta,
+                           const float* reduced_tail, int K, float decay, float one_minus_decay, float eps, float k_eps,
+                           float* usage, float* cluster_size, float* loss_out, float* perplexity_out,
+                           int64_t* counts64_out, int64_t* n_total_out, int32_t* cleanup_control,
+                           uint32_t* cleanup_counts, void* stream);
+
+/*
  * One whole forward of the quantizer in ONE call: vq_codebook_prep -> vq_search -> vq_code_histogram ->
  * (training) vq_ema_scatter[_sorted] -> vq_step_finish -> (training) vq_ema_codebook_update_end, enqueued
  * back to back on `stream`.  ref: vqvae/ema_vector_quantizer.py:33-108, the forward as a whole.  For a host

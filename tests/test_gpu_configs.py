@@ -260,3 +260,109 @@ def test_config4_data_parallel_module_two_ranks(dev):
     assert rel_err(s0["ema_w"], st.ema_w) <= 1e-5
     assert rel_err(s0["ema_cluster_size"], st.ema_cluster_size) <= 1e-5
     assert np.array_equal(s0["usage_count"], st.usage_count)
+
+
+def _dp_boundary_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vq_vae_amd import QuantizerBoundary
+        dev = torch.device("cuda:0")                       # both ranks share the one GPU of the box
+        K, D = 8192, 256
+        m = QuantizerBoundary(D, K, D, ema_decay=0.95, commitment_loss_beta=3.0).to(dev)
+        with torch.no_grad():
+            m.quantize.embedding.weight.copy_(torch.from_numpy(gauss(900, (K, D))))
+            m.quant_conv.weight.copy_(torch.from_numpy(gauss(901, (D, D, 1, 1)) * np.float32(0.06)))
+            m.quant_conv.bias.copy_(torch.from_numpy(gauss(902, (D,)) * np.float32(0.1)))
+            m.post_quant_conv.weight.copy_(torch.from_numpy(gauss(903, (D, D, 1, 1)) * np.float32(0.06)))
+            m.post_quant_conv.bias.copy_(torch.from_numpy(gauss(904, (D,)) * np.float32(0.1)))
+        m.quantize.enable_data_parallel()
+        m.train()
+        conv_params = [m.quant_conv.weight, m.quant_conv.bias, m.post_quant_conv.weight, m.post_quant_conv.bias]
+
+        def step(h_np, w_np):
+            m.zero_grad(set_to_none=True)
+            h = torch.from_numpy(h_np).to(dev).requires_grad_(True)
+            out, loss, (perp, idx, _) = m(h)
+            ((out * torch.from_numpy(w_np).to(dev)).sum() + loss).backward()
+            for p in conv_params:                      # what DistributedDataParallel does: average over the ranks
+                g = p.grad.cpu()
+                dist.all_reduce(g)
+                p.grad.copy_(g / world)
+            torch.cuda.synchronize()
+            return out, loss, perp, idx, h.grad
+
+        # the per-rank batch of 8 images, checked against the oracle on the 16 images of both ranks
+        out, loss, perp, idx, gh = step(gauss(910 + rank, (8, D, 32, 32)), gauss(920 + rank, (8, D, 32, 32)))
+        first = {"loss": float(loss), "perp": float(perp), "idx": idx.cpu().numpy(), "out": out.detach().cpu().numpy(),
+                 "grad_h": gh.cpu().numpy(), "grads": [p.grad.cpu().numpy() for p in conv_params],
+                 "state": {k: v.cpu().numpy() for k, v in m.quantize.state_dict().items()}}
+        # configuration 4's stated per-GPU batch: 64 images of 32 x 32 latents
+        out, loss, perp, idx, gh = step(gauss(930 + rank, (64, D, 32, 32)), gauss(940 + rank, (64, D, 32, 32)))
+        counts = torch.bincount(idx.view(-1), minlength=K).cpu().numpy()
+        second = {"loss": float(loss), "perp": float(perp), "counts": counts,
+                  "grads": [p.grad.cpu().numpy() for p in conv_params],
+                  "state": {k: v.cpu().numpy() for k, v in m.quantize.state_dict().items()}}
+        q.put((rank, first, second))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config4_boundary_segment_data_parallel_at_its_stated_shape(dev):
+    """Configuration 4 through the whole segment: quant_conv -> quantizer (K = 8192, D = 256) -> post_quant_conv
+    (vqvae/custom_vqgan.py:76-114 between encoder and decoder) on two ranks, EMA statistics all-reduced, the
+    convolutions' gradients averaged over the ranks as DistributedDataParallel would.  8 images per rank against
+    the oracle's composition on the 16 images of both ranks; then one step at the stated 64 images per rank.
+    The replicas must stay bit-identical throughout."""
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_boundary_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=280) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, a1, a2), (_, b1, b2) = res
+    # replicas: state and averaged gradients bit for bit, after both steps
+    for x, y in ((a1, b1), (a2, b2)):
+        for k in x["state"]:
+            assert np.array_equal(x["state"][k].view(np.uint8), y["state"][k].view(np.uint8)), k
+        for gx, gy in zip(x["grads"], y["grads"]):
+            assert np.array_equal(gx.view(np.uint8), gy.view(np.uint8))
+        assert x["perp"] == y["perp"]
+    # the oracle on the concatenated batch of step one
+    K, D = 8192, 256
+    Wq, bq = gauss(901, (D, D, 1, 1)) * np.float32(0.06), gauss(902, (D,)) * np.float32(0.1)
+    Wp, bp = gauss(903, (D, D, 1, 1)) * np.float32(0.06), gauss(904, (D,)) * np.float32(0.1)
+    h = np.concatenate([gauss(910 + r, (8, D, 32, 32)) for r in range(world)], 0)
+    w = np.concatenate([gauss(920 + r, (8, D, 32, 32)) for r in range(world)], 0)
+    st = vo.OracleState.fresh(gauss(900, (K, D)))
+    # averaged over two ranks: d/dtheta of (S_0 + S_1) / 2 + (L_0 + L_1) / 2, and (L_0 + L_1) / 2 is the mean over all rows
+    r = vo.boundary(h, Wq, bq, Wp, bp, st, 3.0, 0.95, 1e-5, 1.0, True, grad_out=w / np.float32(world), grad_loss=1.0)
+    idx = np.concatenate([a1["idx"].reshape(-1), b1["idx"].reshape(-1)])
+    assert np.array_equal(idx, r["indices"].reshape(-1))
+    assert rel_err(np.concatenate([a1["out"], b1["out"]], 0), r["out"]) <= 1e-5
+    assert abs((a1["loss"] + b1["loss"]) / 2 - r["loss"]) <= 1e-5 * abs(r["loss"])
+    assert abs(a1["perp"] - r["perplexity"]) <= 1e-5 * r["perplexity"]
+    for got, want in zip(a1["grads"], (r["grad_Wq"], r["grad_bq"], r["grad_Wp"], r["grad_bp"])):
+        assert rel_err(got, want) <= 1e-5
+    # each rank's input gradient: its own loss has weight 1, not 1/2, and the gradient is linear in the two weights
+    gh = np.concatenate([a1["grad_h"], b1["grad_h"]], 0)
+    assert rel_err(gh, np.float32(world) * r["grad_h"]) <= 1e-5
+    assert rel_err(a1["state"]["embedding.weight"], st.embedding) <= 1e-5
+    assert rel_err(a1["state"]["ema_w"], st.ema_w) <= 1e-5
+    assert rel_err(a1["state"]["ema_cluster_size"], st.ema_cluster_size) <= 1e-5
+    assert np.array_equal(a1["state"]["usage_count"], st.usage_count)
+    # step two (64 images per rank): every row counted once on each rank, usage grew by all 128 Ki rows of both ranks
+    assert int(a2["counts"].sum()) == 64 * 1024 and int(b2["counts"].sum()) == 64 * 1024
+    grown = a2["state"]["usage_count"].astype(np.float64).sum() - a1["state"]["usage_count"].astype(np.float64).sum()
+    assert grown == 2 * 64 * 1024
+    assert np.array_equal(a2["state"]["usage_count"] - a1["state"]["usage_count"], (a2["counts"] + b2["counts"]).astype(np.float32))
+    assert np.isfinite(a2["loss"]) and np.isfinite(a2["perp"]) and all(np.isfinite(g).all() for g in a2["grads"])

@@ -65,6 +65,11 @@ SIGNATURES = {
     "vq_ema_codebook_update_end": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p]),
     "vq_quantize_step": (c_int, [c_void_p, c_void_p]),
+    "vq_packed_stats_floats": (c_size_t, [c_int, c_int, c_int]),
+    "vq_pack_stats": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
+    "vq_step_finish_reduced": (c_int, [c_void_p, c_int64, c_int64, c_int, c_float, c_void_p, c_int, c_float, c_float,
+                                       c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p]),
     "vq_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p]),
     "vq_gather_project": (c_int, [c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                   c_void_p, c_void_p, c_void_p]),

@@ -50,6 +50,8 @@ class _QuantizeProjectFn(torch.autograd.Function):
         E_pre = E.clone() if (needs[0] or needs[1] or needs[2]) else E
         P = E @ W.t() if bias is None else torch.addmm(bias.detach().float(), E, W.t())
         res = module._run_step(z, temperature, project=P)
+        if res.finish is not None:       # data-parallel mode: the EMA update behind the all-reduce
+            res.finish()
         ctx.save_for_backward(z, res.indices, E_pre, weight)
         ctx.has_bias = bias is not None
         ctx.ws = module._workspace(z.device)

@@ -482,6 +482,75 @@ __global__ __launch_bounds__(1024) void vq_step_finish_kernel(const float* __res
   vq_step_cleanup(cleanup_control, cleanup_counts, K, t, 1024);
 }
 
+// ---- data-parallel exchange: pack before the all-reduce, finish from the reduced buffer after it ----
+// buf = [dw (K*D) | counts mod 4096 (K) | counts div 4096 (K) | rows mod 4096 | rows div 4096], all fp32.
+// Both halves of a count sum to integers below 2^24 for up to 4096 ranks of fewer than 2^24 rows each, and
+// fp32 adds such integers exactly, so ONE fp32 SUM all-reduce carries the embedding sums, the exact code
+// counts and the exact global row count.
+__global__ __launch_bounds__(256) void vq_pack_stats_kernel(const float* __restrict__ slabs, int nslab, int64_t KD,
+                                                            const uint32_t* __restrict__ counts, int K, int64_t n_local,
+                                                            float* __restrict__ buf) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < KD) {
+    float v = slabs[i];
+    for (int t = 1; t < nslab; ++t) v += slabs[(size_t)t * KD + i];   // slab order, as vq_reduce_slabs
+    buf[i] = v;
+  } else if (i < KD + K) {
+    buf[i] = (float)(counts[i - KD] & 4095u);
+  } else if (i < KD + 2 * (int64_t)K) {
+    buf[i] = (float)(counts[i - KD - K] >> 12);
+  } else if (i == KD + 2 * (int64_t)K) {
+    buf[i] = (float)(n_local & 4095);
+    buf[i + 1] = (float)(n_local >> 12);
+  }
+}
+
+// After the all-reduce: loss of the local batch, perplexity and cluster sizes from the reduced counts
+// (the arithmetic of vq_step_finish, with counts and the row total read from the buffer's tail).
+__global__ __launch_bounds__(1024) void vq_step_finish_reduced_kernel(
+    const float* __restrict__ loss_partial, int64_t n_partial, int64_t N_local, int D, float beta,
+    const float* __restrict__ tail, int K, float decay, float omd, float eps, float k_eps, float* __restrict__ usage,
+    float* __restrict__ cs, float* loss_out, float* perplexity_out, int64_t* __restrict__ counts64_out,
+    int64_t* n_total_out, int32_t* cleanup_control, uint32_t* cleanup_counts) {
+  __shared__ double sh[1024];
+  const int t = threadIdx.x;
+  if (loss_partial && loss_out) {
+    double s = 0.0;
+    for (int64_t i = t; i < n_partial; i += 1024) s += (double)loss_partial[i];
+    const double tot = block_sum_1024(s, sh);
+    if (t == 0) *loss_out = beta * (float)(tot / ((double)N_local * (double)D));   // ref :92, local-batch mean
+  }
+  const int64_t n_total = (int64_t)tail[2 * K] + ((int64_t)tail[2 * K + 1] << 12);
+  if (t == 0 && n_total_out) *n_total_out = n_total;
+  auto count_of = [&](int k) -> int64_t { return (int64_t)tail[k] + ((int64_t)tail[K + k] << 12); };
+  if (perplexity_out) {
+    double s = 0.0;
+    const float nf = (float)n_total;
+    for (int k = t; k < K; k += 1024) {
+      const float p = (float)count_of(k) / nf;         // ref :105 over the global batch
+      s += (double)(p * logf(p + 1e-10f));             // ref :106
+    }
+    const double tot = block_sum_1024(s, sh);
+    if (t == 0) *perplexity_out = expf(-(float)tot);
+  }
+  if (counts64_out)
+    for (int k = t; k < K; k += 1024) counts64_out[k] = count_of(k);
+  if (usage != nullptr) {
+    double s = 0.0;
+    for (int k = t; k < K; k += 1024) {
+      const float c = (float)count_of(k);
+      usage[k] = usage[k] + c;                       // ref :67
+      const float v = cs[k] * decay + omd * c;       // ref :71-72
+      cs[k] = v;
+      s += (double)v;
+    }
+    const float n = (float)block_sum_1024(s, sh);    // ref :75
+    const float denom = n + k_eps;
+    for (int k = t; k < K; k += 1024) cs[k] = (cs[k] + eps) / denom * n;  // ref :76-80, stored back
+  }
+  vq_step_cleanup(cleanup_control, cleanup_counts, K, t, 1024);
+}
+
 __global__ __launch_bounds__(256) void vq_codebook_update_end_kernel(const float* __restrict__ slabs, int nslab, int K,
                                                                      int D, float decay, float omd,
                                                                      const float* __restrict__ cs,
@@ -786,6 +855,37 @@ int vq_ema_codebook_update_end(const float* slabs, int nslab, int K, int D, floa
   hipLaunchKernelGGL(vq_codebook_update_end_kernel, dim3((unsigned)((KD + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, slabs, nslab, K, D, decay, one_minus_decay, cluster_size, ema_w, E,
                      cleanup_control, cleanup_counts);
+  return vq_hip_status(hipGetLastError());
+}
+
+size_t vq_packed_stats_floats(int K, int D, int with_sums) {
+  if (K <= 0 || D <= 0) return 0;
+  return (size_t)(with_sums ? (int64_t)K * D : 0) + 2 * (size_t)K + 2;
+}
+
+int vq_pack_stats(const float* slabs, int nslab, int K, int D, const uint32_t* counts, int64_t n_local, float* buf,
+                  void* stream) {
+  if (!counts || !buf || K <= 0 || D <= 0 || n_local < 0) return VQ_ERR_INVALID_ARG;
+  if (slabs != nullptr && nslab <= 0) return VQ_ERR_INVALID_ARG;
+  if (n_local >= ((int64_t)1 << 24)) return VQ_ERR_UNSUPPORTED;     // a count's upper half must stay below 2^12
+  const int64_t KD = slabs ? (int64_t)K * D : 0;
+  const int64_t total = KD + 2 * (int64_t)K + 2;
+  hipLaunchKernelGGL(vq_pack_stats_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, slabs,
+                     nslab, KD, counts, K, n_local, buf);
+  return vq_hip_status(hipGetLastError());
+}
+
+int vq_step_finish_reduced(const float* loss_partial, int64_t n_partial, int64_t N_local, int D, float beta,
+                           const float* reduced_tail, int K, float decay, float one_minus_decay, float eps, float k_eps,
+                           float* usage, float* cluster_size, float* loss_out, float* perplexity_out,
+                           int64_t* counts64_out, int64_t* n_total_out, int32_t* cleanup_control,
+                           uint32_t* cleanup_counts, void* stream) {
+  if (!reduced_tail || K <= 0 || D <= 0 || N_local < 0) return VQ_ERR_INVALID_ARG;
+  if ((usage == nullptr) != (cluster_size == nullptr)) return VQ_ERR_INVALID_ARG;
+  if (loss_partial && loss_out && N_local == 0) return VQ_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(vq_step_finish_reduced_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, loss_partial, n_partial,
+                     N_local, D, beta, reduced_tail, K, decay, one_minus_decay, eps, k_eps, usage, cluster_size, loss_out,
+                     perplexity_out, counts64_out, n_total_out, cleanup_control, cleanup_counts);
   return vq_hip_status(hipGetLastError());
 }
 

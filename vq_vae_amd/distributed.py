@@ -95,6 +95,19 @@ def make_stats_reduce(group: Optional[dist.ProcessGroup] = None, uneven_rows: bo
             _all_reduce(dw, dist.ReduceOp.SUM, group)
         return counts64, dw, n_total
 
+    def reduce_packed(buf: torch.Tensor):
+        """SUM all-reduce of a buffer the library packed on the device (vq_pack_stats).  Over RCCL the
+        collective is issued asynchronously, on the backend's own stream, and the function returned makes
+        the caller's current stream wait for it: whatever the caller enqueues in between runs beside the
+        exchange.  (gloo, with ranks sharing a GPU: a blocking host round trip.)"""
+        if buf.is_cuda and dist.get_backend(group) != "gloo":
+            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True)
+            return work.wait
+        _all_reduce(buf, dist.ReduceOp.SUM, group)
+        return lambda: None
+
+    reduce.reduce_packed = reduce_packed
+    reduce.world_size = lambda: dist.get_world_size(group)
     return reduce
 
 

@@ -118,6 +118,7 @@ class _QuantizeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z: torch.Tensor, module: "EMAVectorQuantizer", temperature: float):
         res = module._run_step(z, temperature)
+        module._pending_finish = res.finish     # data-parallel mode: the all-reduce is in flight (see forward)
         ctx.save_for_backward(z, res.quantized)
         ctx.coef = 2.0 * float(module.commitment_cost) / float(max(z.numel(), 1))
         ctx.mark_non_differentiable(res.perplexity, res.indices)
@@ -206,7 +207,8 @@ class EMAVectorQuantizer(nn.Module):
                                  beta=float(self.commitment_cost), decay=float(self.decay),
                                  epsilon=float(self.epsilon), temperature=float(temperature),
                                  training=self.training, ws=self._workspace(z.device),
-                                 stats_reduce=self._stats_reduce, filtered=self._use_filter(z), project=project)
+                                 stats_reduce=self._stats_reduce, filtered=self._use_filter(z), project=project,
+                                 defer_finish=self._stats_reduce is not None)
 
     def forward(self, inputs, temperature=1.0):
         if not isinstance(inputs, torch.Tensor) or not inputs.is_cuda:
@@ -230,7 +232,15 @@ class EMAVectorQuantizer(nn.Module):
             encodings = ops.onehot(idx, self.num_embeddings)
         else:
             encodings = LazyOneHot(idx, self.num_embeddings)
+        self._finish_pending()      # data-parallel mode: the one-hot matrix was written beside the all-reduce
         return quantized, loss, (perplexity, encoding_indices, encodings)
+
+    def _finish_pending(self) -> None:
+        """Data-parallel mode: enqueue what waits for the all-reduce of the EMA statistics (loss, perplexity,
+        the EMA update).  Always done before forward returns."""
+        fin, self._pending_finish = getattr(self, "_pending_finish", None), None
+        if fin is not None:
+            fin()
 
     # ------------------------------------------------------------------ statistics
     def get_codebook_stats(self):

@@ -100,6 +100,10 @@ class StepResult:
     indices: torch.Tensor         # [N] int64
     counts: torch.Tensor          # [K] int32 bit pattern of uint32 counts
     dmin: Optional[torch.Tensor] = None
+    #: data-parallel step asked to defer: enqueues the wait for the all-reduce and the kernels behind it
+    #: (loss, perplexity, EMA update).  Call it before anything reads those -- work enqueued before the call
+    #: runs beside the exchange.
+    finish: Optional[object] = None
 
 
 def _shape_of(z: torch.Tensor, D: int):
@@ -546,7 +550,7 @@ def conv1x1_wgrad(gy: torch.Tensor, x: torch.Tensor, ws: Workspace, want_bias: b
 def quantize_step(z: torch.Tensor, E: torch.Tensor, ema_w, cluster_size, usage, *, beta: float, decay: float,
                   epsilon: float, temperature: float, training: bool, ws: Workspace, want_dmin: bool = False,
                   stats_reduce=None, search_events=None, filtered: bool = False,
-                  project: Optional[torch.Tensor] = None) -> StepResult:
+                  project: Optional[torch.Tensor] = None, defer_finish: bool = False) -> StepResult:
     """One full forward of the quantizer: search, gather, loss, histogram, perplexity and, in
     training mode, the EMA update of (usage, cluster_size, ema_w, E) in place.
 
@@ -568,7 +572,7 @@ def quantize_step(z: torch.Tensor, E: torch.Tensor, ema_w, cluster_size, usage, 
         out = quantize_step(rows, E, ema_w, cluster_size, usage, beta=beta, decay=decay, epsilon=epsilon,
                             temperature=temperature, training=training, ws=ws, want_dmin=want_dmin,
                             stats_reduce=stats_reduce, search_events=search_events, filtered=filtered,
-                            project=project)
+                            project=project, defer_finish=defer_finish)
         out.quantized = back(out.quantized)
         return out
     if z.numel() == 0:
@@ -576,6 +580,9 @@ def quantize_step(z: torch.Tensor, E: torch.Tensor, ema_w, cluster_size, usage, 
     if stats_reduce is None:
         return _local_step(z, E, ema_w, cluster_size, usage, beta, decay, epsilon, temperature, training, ws,
                            want_dmin, search_events, filtered, project)
+    if hasattr(stats_reduce, "reduce_packed"):
+        return _dp_step(z, E, ema_w, cluster_size, usage, beta, decay, epsilon, temperature, training, ws, want_dmin,
+                        search_events, filtered, project, stats_reduce, defer_finish)
     r = search(z, E, ws, temperature=temperature, want_quantized=project is None, want_dmin=want_dmin,
                events=search_events, filtered=filtered)
     if project is not None:
@@ -648,6 +655,67 @@ def _local_step(z, E, ema_w, cluster_size, usage, beta, decay, epsilon, temperat
     return StepResult(r["quantized"], loss, perp, r["indices"], counts, r["dmin"])
 
 
+def _dp_step(z, E, ema_w, cluster_size, usage, beta, decay, epsilon, temperature, training, ws, want_dmin, search_events,
+             filtered, project, stats_reduce, defer_finish) -> StepResult:
+    """The data-parallel step: search and local statistics, vq_pack_stats, ONE fp32 all-reduce, then
+    vq_step_finish_reduced and the codebook update from the reduced buffer -- every rank applies the same
+    update, so the replicas stay bit-identical without a broadcast.  Packing, unpacking, the row total and the
+    housekeeping are the library's kernels; the host only issues the collective."""
+    lib = _lib.load()
+    K, D = E.shape
+    dev = z.device
+    s = _stream(dev)
+    control = ws.get("control", lib.vq_control_bytes(), torch.int32)
+    both = ws.get("counts2", 2 * K * 4, torch.int32)[: 2 * K].view(2, K)
+    if not ws.clean or ws.counts_k != K:
+        check(lib.vq_control_reset(_ptr(control), s), "vq_control_reset")
+        both.zero_()
+        ws.counts_k = K
+    ws.clean = False
+    counts, counts_next = both[ws.flip], both[1 - ws.flip]
+    prepared = prepare_codebook(E, ws, reset=False)
+    r = search(z, E, ws, temperature=temperature, want_quantized=project is None, want_dmin=want_dmin,
+               events=search_events, filtered=filtered, prepared=prepared)
+    if project is not None:
+        r["quantized"], r["loss_partial"], r["n_partial"] = gather_project(z, E, r["indices"], project, ws)
+    N = r["N"]
+    check(lib.vq_code_histogram(_ptr(r["idx32"]), 0, N, K, _ptr(counts), 1, _ptr(control), s), "vq_code_histogram")
+    slabs, nslab = None, 0
+    if training:
+        slabs, nslab = embed_sums(_f32c(z, "latents"), r["idx32"], K, ws, zmax_valid=r["zmax_valid"])
+    kd = K * D if training else 0
+    buf = ws.get("dp_buf", lib.vq_packed_stats_floats(K, D, 1 if training else 0) * 4, torch.float32)
+    check(lib.vq_pack_stats(_ptr(slabs), nslab, K, D, _ptr(counts), N, _ptr(buf), s), "vq_pack_stats")
+    wait = stats_reduce.reduce_packed(buf)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    perp = torch.empty((), dtype=torch.float32, device=dev)
+    d, omd, eps, keps = ema_scalars(K, decay, epsilon)
+    lp, n_partial = r["loss_partial"], r["n_partial"]
+
+    def finish():
+        wait()
+        tail = ctypes.c_void_p(buf.data_ptr() + kd * 4)
+        if training:
+            check(lib.vq_step_finish_reduced(_ptr(lp), n_partial, N, D, float(np.float32(beta)), tail, K, d, omd, eps,
+                                             keps, _ptr(usage), _ptr(cluster_size), _ptr(loss), _ptr(perp), None, None,
+                                             None, None, s), "vq_step_finish_reduced")
+            check(lib.vq_ema_codebook_update_end(_ptr(buf), 1, K, D, d, omd, _ptr(cluster_size), _ptr(ema_w), _ptr(E),
+                                                 _ptr(control), _ptr(counts_next), s), "vq_ema_codebook_update_end")
+        else:
+            check(lib.vq_step_finish_reduced(_ptr(lp), n_partial, N, D, float(np.float32(beta)), tail, K, d, omd, eps,
+                                             keps, None, None, _ptr(loss), _ptr(perp), None, None, _ptr(control),
+                                             _ptr(counts_next), s), "vq_step_finish_reduced")
+        ws.clean = True
+        ws.flip = 1 - ws.flip
+
+    out = StepResult(r["quantized"], loss, perp, r["indices"], counts, r["dmin"])
+    if defer_finish:
+        out.finish = finish
+    else:
+        finish()
+    return out
+
+
 def _single_call_step(lib, z, E, ema_w, cluster_size, usage, beta, decay, epsilon, temperature, training, ws, want_dmin,
                       control, both, s) -> StepResult:
     """The same step through vq_quantize_step: one call into the library, which enqueues the kernels back to
@@ -714,6 +782,25 @@ def _empty_step(z, E, ema_w, cluster_size, usage, decay, epsilon, training, ws, 
     nan = torch.full((), float("nan"), dtype=torch.float32, device=dev)
     counts = ws.get("counts", K * 4, torch.int32)[:K]
     counts.zero_()
+    if stats_reduce is not None and hasattr(stats_reduce, "reduce_packed"):
+        # this rank has no rows but the others do: take part in the same exchange with all-zero statistics
+        lib = _lib.load()
+        s = _stream(dev)
+        kd = K * D if training else 0
+        buf = ws.get("dp_buf", lib.vq_packed_stats_floats(K, D, 1 if training else 0) * 4, torch.float32)
+        buf.zero_()
+        stats_reduce.reduce_packed(buf)()
+        perp = torch.empty((), dtype=torch.float32, device=dev)
+        d, omd, eps, keps = ema_scalars(K, decay, epsilon)
+        tail = ctypes.c_void_p(buf.data_ptr() + kd * 4)
+        check(lib.vq_step_finish_reduced(None, 0, 0, D, 0.0, tail, K, d, omd, eps, keps, _ptr(usage) if training else None,
+                                         _ptr(cluster_size) if training else None, None, _ptr(perp), None, None, None, None,
+                                         s), "vq_step_finish_reduced")
+        if training:
+            check(lib.vq_ema_codebook_update_end(_ptr(buf), 1, K, D, d, omd, _ptr(cluster_size), _ptr(ema_w), _ptr(E),
+                                                 None, None, s), "vq_ema_codebook_update_end")
+        ws.clean = False
+        return StepResult(q, nan, perp, torch.empty(0, dtype=torch.int64, device=dev), counts, None)
     if training:
         dw = ws.get("dw", K * D * 4, torch.float32)[: K * D].view(K, D)
         dw.zero_()
