@@ -150,7 +150,7 @@ def test_training_step_through_the_module_uses_the_kernel(env):
         q, loss, (perp, idx, _) = m(z, temperature=2.5)
         (q.square().sum() * 1e-3 + loss).backward()
         torch.cuda.synchronize()
-        res.append((q.detach(), float(loss), float(perp), idx, z.grad, m.embedding.weight.detach().clone(),
+        res.append((q.detach(), float(loss.detach()), float(perp.detach()), idx, z.grad, m.embedding.weight.detach().clone(),
                     m.ema_w.clone(), m.ema_cluster_size.clone(), m.usage_count.clone()))
     lib.vq_internal_tune(0, 1)
     a, b = res

@@ -7,11 +7,11 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from vq_vae_amd import ops  # noqa: E402
+from vq_vae_amd import _lib, ops  # noqa: E402
 
 
-def timed(fn, reps=5):
-    for _ in range(2):
+def timed(fn, reps=20):
+    for _ in range(5):
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -34,6 +34,12 @@ def main():
         E = torch.randn(K, D, device=dev, generator=g)
         ms = timed(lambda: ops.search(z, E, ws, want_quantized=True))
         line = f"{K:5d}, {D:3d}: {ms:8.3f} ms ({2.0 * N * K * D / ms / 1e9:6.1f} TFLOP/s, {N / ms / 1e3:7.1f} M vec/s)"
+        if K <= 1024 and D in (16, 32, 64, 128, 256):
+            # short sweeps run the persistent kernel; the one-workgroup-per-tile kernel on the same input for comparison
+            lib = _lib.load()
+            lib.vq_internal_tune(0, 0)
+            line += f" [one-tile kernel {timed(lambda: ops.search(z, E, ws, want_quantized=True)):.3f} ms]"
+            lib.vq_internal_tune(0, 1)
         if D in (64, 128, 256) and K >= 512:
             fm = timed(lambda: ops.search(z, E, ws, want_quantized=True, filtered=True))
             line += f" | {fm:7.3f} ms"
