@@ -60,7 +60,7 @@ int vq_large_lds_kernels(void);
 size_t vq_image_bytes(int K, int D);            /* codebook image, the search's MFMA A operand     */
 size_t vq_norms_bytes(int K);                   /* squared norms of the (padded) codebook          */
 int64_t vq_search_blocks(int64_t N);            /* workgroups of vq_search = loss partials it writes*/
-size_t vq_loss_partial_bytes(int64_t N);        /* floats: vq_search_blocks(N) + fix-up partials   */
+size_t vq_loss_partial_bytes(int64_t N);        /* floats: the sweep's partials + the exact kernel's */
 size_t vq_control_bytes(void);                  /* small block of control words                    */
 size_t vq_search_split_bytes(int64_t N, int K); /* scratch of the codebook split (0: this N, K is not split) */
 int vq_scatter_slabs(int64_t N, int K, int D);  /* number of partial-sum slabs vq_ema_scatter writes (NCHW)*/

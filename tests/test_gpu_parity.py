@@ -446,3 +446,63 @@ def test_temperature_fuzz_against_the_exact_kernel(dev, ops):
         assert torch.equal(d_f.view(torch.int32), exact["dmin"].view(torch.int32)), (trial, K, D, T)
     o_idx, o_d = vo.search(z, E, T)          # and the last trial against the oracle
     assert np.array_equal(i_f.cpu().numpy(), o_idx) and np.array_equal(_bits(d_f.cpu().numpy()), _bits(o_d))
+
+
+@pytest.mark.parametrize("images,K,D,rows_layout", [(64, 8192, 64, False), (64, 4096, 128, True), (64, 1000, 48, False),
+                                                    (128, 512, 256, False), (128, 64, 256, True), (128, 1000, 32, False)])
+def test_deferred_temperature_on_large_batches(images, K, D, rows_layout, dev, ops):
+    """Batches large enough for the undivided sweeps (whole codebook per workgroup, and the persistent kernel at
+    K <= 1024) with T != 1: the kernels compare undivided distances, divide the winner only and hand rows with a
+    code close above the minimum to the exact kernel.  Against the exact kernel's literal division
+    (vqvae/ema_vector_quantizer.py:49-53), indices and quotients bit for bit, on a random codebook and on one of
+    near-duplicate clusters where quotients collide and the lower index must win."""
+    rng = np.random.default_rng(1900 + K + D)
+    ws = ops.Workspace(dev)
+    z = gauss(1901 + K, (images, D, 32, 32))
+    if rows_layout:
+        z = np.ascontiguousarray(z.transpose(0, 2, 3, 1).reshape(-1, D))
+    zt = _t(z, dev)
+    sent = []
+    for clustered, T in ((False, 2.5), (True, 2.5), (True, 0.3), (True, 77.0)):
+        if clustered:
+            centers = gauss(1950 + K, ((K + 15) // 16, D))
+            E = np.repeat(centers, 16, axis=0)[:K] * (1 + rng.integers(-3, 4, (K, 1)).astype(np.float32) * np.float32(2 ** -23))
+            E = np.ascontiguousarray(E.astype(np.float32))
+        else:
+            E = gauss(1950 + K, (K, D))
+        Et = _t(E, dev)
+        fast = ops.search(zt, Et, ws, temperature=T, want_quantized=True, want_dmin=True)
+        sent.append(int(fast["control"][0].item()) + int(fast["control"][6].item()))   # both lists of the exact kernel
+        i_f, d_f, q_f = fast["indices"].clone(), fast["dmin"].clone(), fast["quantized"].clone()
+        exact = ops.search(zt, Et, ws, temperature=T, want_quantized=True, want_dmin=True, exact=True)
+        torch.cuda.synchronize()
+        assert torch.equal(i_f, exact["indices"]), (clustered, T)
+        assert torch.equal(d_f.view(torch.int32), exact["dmin"].view(torch.int32)), (clustered, T)
+        assert torch.equal(q_f.view(torch.int32), exact["quantized"].view(torch.int32)), (clustered, T)
+    # a random codebook sends next to nothing to the exact kernel, the clustered ones a good share of the rows
+    assert sent[0] <= max(64, images * 1024 // 1000), sent
+    assert min(sent[1:]) > 0, sent
+    # a few dozen such rows (the exact kernel then shares each row out over several workgroups): a few pairs of
+    # codes some units in the last place apart, the copy at the lower index -- latents whose nearest code is the later
+    # one of a pair, by less than the quotients can tell apart, are the ones that need the literal division
+    E = gauss(1950 + K, (K, D))
+    for pair in range(max(1, K // 1024)):
+        lo, hi = 7 + 37 * pair, K // 2 + 11 + 53 * pair
+        E[lo] = E[hi] * (1 + rng.integers(-2, 3, (D,)).astype(np.float32) * np.float32(2 ** -23))
+    z2 = z
+    zt2, Et = _t(z2, dev), _t(E, dev)
+    for T in (2.5, 0.7):
+        fast = ops.search(zt2, Et, ws, temperature=T, want_quantized=True, want_dmin=True)
+        n_close = int(fast["control"][6].item())
+        i_f, d_f, q_f, lp_f = fast["indices"].clone(), fast["dmin"].clone(), fast["quantized"].clone(), fast["loss_partial"].clone()
+        lp = lp_f.double().sum().item()
+        exact = ops.search(zt2, Et, ws, temperature=T, want_quantized=True, want_dmin=True, exact=True)
+        torch.cuda.synchronize()
+        assert n_close >= 1 and (n_close <= 512 or K < 512), n_close      # (K < 512: one workgroup per row whatever the count)
+        assert torch.equal(i_f, exact["indices"]) and torch.equal(d_f.view(torch.int32), exact["dmin"].view(torch.int32))
+        assert torch.equal(q_f.view(torch.int32), exact["quantized"].view(torch.int32))
+        assert abs(lp - exact["loss_partial"].double().sum().item()) <= 1e-6 * abs(lp)
+        again = ops.search(zt2, Et, ws, temperature=T, want_quantized=True, want_dmin=True)
+        if K >= 512:
+            # each such row has a partial of its own whatever workgroup wrote it (their order follows the list's)
+            assert torch.equal(torch.sort(again["loss_partial"]).values, torch.sort(lp_f).values)

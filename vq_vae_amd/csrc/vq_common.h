@@ -19,6 +19,8 @@ constexpr int VQ_WG_ROWS = 256;
 constexpr float VQ_NORM_LIMIT = 1.0e30f;
 // Workgroups of the exact (fix-up) kernel when it walks the list of flagged rows.
 constexpr int VQ_FIX_WGS = 1024;
+// loss partials of rows that several workgroups of the exact kernel share (one slot per row)
+constexpr int VQ_NEAR_SLOTS = VQ_FIX_WGS / 2;
 
 __host__ __device__ inline int vq_kpad(int K) { return (K + VQ_STAGE_CODES - 1) / VQ_STAGE_CODES * VQ_STAGE_CODES; }
 // One stage of the codebook image: 64 codes x D floats in MFMA-fragment order, then the
@@ -34,7 +36,7 @@ __host__ __device__ inline int vq_pad_dim(int D) {
 }
 
 // Control words shared by the kernels of one step (device memory, 16 ints).
-enum { VQ_CTL_NF_COUNT = 0, VQ_CTL_CB_FLAG = 1, VQ_CTL_BAD_INDEX = 2, VQ_CTL_ZMAX = 3, VQ_CTL_OVF_COUNT = 4, VQ_CTL_OVF2_COUNT = 5, VQ_CTL_WORDS = 16 };
+enum { VQ_CTL_NF_COUNT = 0, VQ_CTL_CB_FLAG = 1, VQ_CTL_BAD_INDEX = 2, VQ_CTL_ZMAX = 3, VQ_CTL_OVF_COUNT = 4, VQ_CTL_OVF2_COUNT = 5, VQ_CTL_NEAR_COUNT = 6, VQ_CTL_WORDS = 16 };
 
 static inline int vq_hip_status(hipError_t e) { return e == hipSuccess ? VQ_OK : VQ_ERR_HIP_BASE + (int)e; }
 

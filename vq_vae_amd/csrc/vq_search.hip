@@ -61,6 +61,11 @@ struct SearchArgs {
   // unsettled (control[VQ_CTL_OVF_COUNT]); rows the verification already handed to the exact
   // kernel (marked -2 in idx32) are skipped without a new list entry
   int fallback_role;
+  // deferred temperature: rows with a code close above the minimum are listed from the END of nf_rows backwards
+  // (control[VQ_CTL_NEAR_COUNT] entries) and redone one per workgroup with every distance divided; a channel
+  // count that the per-row routine does not take (near_ok == 0) sends them to the front list instead
+  int near_ok;
+  float* near_loss;     // VQ_NEAR_SLOTS loss partials for such rows (zeroed by the sweep, which counts them as unused slots)
 };
 
 // The filtered search gives up on a batch whose first pass left more than an eighth of the rows
@@ -101,9 +106,23 @@ __device__ __forceinline__ void stage_copy(const float* image, int stage, float*
 
 // Scan one finished 32-code x 32-latent accumulator tile.  Register r of the tile is code
 // row (r&3) + 8*(r>>2) + 4*(lane>>5); the 4*(lane>>5) part is added once after the sweep.
-template <bool TEMP, bool PAIRWISE>
+//
+// TEMP: how a temperature T != 1 (finite, > 0) enters.
+//   VQ_T_NONE     T = 1.
+//   VQ_T_LITERAL  every distance is divided by T before it is compared, as the reference writes it.
+//   VQ_T_DEFERRED distances are compared undivided, and `sec` keeps the value that the running minimum
+//                 displaced last.  Division by T > 0 with one rounding is monotone, so the smallest quotient is
+//                 that of the smallest distance m, and the reference's winner is the first code whose quotient
+//                 equals it.  That is the first code at distance m unless some code before it lies so close
+//                 above m that the two quotients round to the same number -- and the first such code of a scan
+//                 in index order was a running minimum when it was met (everything before it is farther), so
+//                 it or a later, smaller running minimum is what `sec` holds at the end.  The caller tests
+//                 sec against m (vq_t_near) and sends the few rows that fail to the exact kernel.
+enum { VQ_T_NONE = 0, VQ_T_LITERAL = 1, VQ_T_DEFERRED = 2 };
+
+template <int TEMP, bool PAIRWISE>
 __device__ __forceinline__ void scan_tile(const f32x16& c, const f32x4 (&e2v)[4], float z2, int code0, float T,
-                                          int self_code, float& best, int& bidx, double& psum, float& pmin,
+                                          int self_code, float& best, int& bidx, float& sec, double& psum, float& pmin,
                                           float& pmax) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -111,7 +130,7 @@ __device__ __forceinline__ void scan_tile(const f32x16& c, const f32x4 (&e2v)[4]
     for (int r = 0; r < 4; ++r) {
       const float t = z2 + e2v[q][r];
       float d = __builtin_fmaf(-2.0f, c[4 * q + r], t);
-      if (TEMP) d = d / T;
+      if (TEMP == VQ_T_LITERAL) d = d / T;
       const int code = code0 + 8 * q + r;
       if (PAIRWISE) {
         const bool real = (e2v[q][r] < __builtin_inff()) && (code != self_code);
@@ -124,10 +143,34 @@ __device__ __forceinline__ void scan_tile(const f32x16& c, const f32x4 (&e2v)[4]
         }
       }
       const bool tk = d < best;
+      if (TEMP == VQ_T_DEFERRED) sec = tk ? best : sec;
       best = tk ? d : best;
       bidx = tk ? code : bidx;
     }
   }
+}
+
+// Deferred temperature: two finished scans of disjoint code sets (best_a, sec_a) and (best_b, sec_b) become
+// one -- the smaller of the two minima is the minimum, and the closest value above it that either scan knows of
+// is the other minimum (when it differs) or one of the two displaced values.
+__device__ __forceinline__ float vq_t_merge_sec(float best_a, float sec_a, float best_b, float sec_b) {
+  const float lo = best_a < best_b ? best_a : best_b;
+  const float hi = best_a < best_b ? best_b : best_a;
+  float sec = sec_a < sec_b ? sec_a : sec_b;
+  if (hi > lo && hi < sec) sec = hi;
+  return sec;
+}
+
+// Deferred temperature: may a code at distance sec > m have the same quotient by T as one at distance m?
+// With u = 2^-24, a quotient of normal size is rounded by at most a factor 1 +- u, so two distances more than
+// a factor (1 + u) / (1 - u) < 1 + 2^-22 apart keep their order strictly (for m < 0 the same bound holds on
+// the absolute errors); gap and 2^-22 |m| are both exact in fp32.  Below normal size the quotients' spacing is
+// absolute (2^-149), and a quotient that overflows equals every other that does.  q = m / T as computed.
+__device__ __forceinline__ bool vq_t_near(float m, float sec, float T, float q) {
+  const float gap = sec - m;                       // exact when the two are close
+  const float am = m < 0.0f ? -m : m;
+  const float aq = q < 0.0f ? -q : q;
+  return gap <= 2.384185791015625e-07f * am || gap <= T * 7.888609052210118e-31f || !(aq < __builtin_inff());
 }
 
 // CT = 32-latent column tiles per wave.  CT = 2: 4 waves, one per SIMD, 512 registers each.
@@ -135,7 +178,7 @@ __device__ __forceinline__ void scan_tile(const f32x16& c, const f32x4 (&e2v)[4]
 // scan, DMA issue and LDS waits.
 // PAD: z and E have a.Dreal < D channels in memory; the image carries zeros in channels Dreal .. D-1, the
 // tile's registers for those channels are zero, and the tail takes the winning code's values from the image.
-template <int D, int CT, bool NCHW, bool TEMP, bool PAIRWISE, bool PAD = false>
+template <int D, int CT, bool NCHW, int TEMP, bool PAIRWISE, bool PAD = false>
 __global__ __launch_bounds__(512 / CT, 2 / CT) void vq_search_mfma_kernel(SearchArgs a) {
   constexpr int NW = 8 / CT;  // waves per workgroup
   constexpr int S = D / 2;  // k-steps of the 32x32x2 MFMA
@@ -246,6 +289,7 @@ __global__ __launch_bounds__(512 / CT, 2 / CT) void vq_search_mfma_kernel(Search
   }
 
   float best[CT];
+  float sec[CT];               // deferred temperature: the value the running minimum displaced last
   int bidx[CT];
   double psum[CT];
   float pmin[CT], pmax[CT];
@@ -253,6 +297,7 @@ __global__ __launch_bounds__(512 / CT, 2 / CT) void vq_search_mfma_kernel(Search
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
     best[ct] = __builtin_inff();
+    sec[ct] = __builtin_inff();
     bidx[ct] = 0;
     psum[ct] = 0.0;
     pmin[ct] = __builtin_inff();
@@ -306,7 +351,7 @@ __global__ __launch_bounds__(512 / CT, 2 / CT) void vq_search_mfma_kernel(Search
       const int code0 = (st0 + st - 1) * VQ_STAGE_CODES + 32;
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)
-        scan_tile<TEMP, PAIRWISE>(cB[ct], e2B, z2[ct], code0, a.T, self_code[ct], best[ct], bidx[ct], psum[ct],
+        scan_tile<TEMP, PAIRWISE>(cB[ct], e2B, z2[ct], code0, a.T, self_code[ct], best[ct], bidx[ct], sec[ct], psum[ct],
                                   pmin[ct], pmax[ct]);
     }
 
@@ -335,7 +380,7 @@ __global__ __launch_bounds__(512 / CT, 2 / CT) void vq_search_mfma_kernel(Search
       const int code0 = (st0 + st) * VQ_STAGE_CODES;
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)
-        scan_tile<TEMP, PAIRWISE>(cA[ct], e2A, z2[ct], code0, a.T, self_code[ct], best[ct], bidx[ct], psum[ct],
+        scan_tile<TEMP, PAIRWISE>(cA[ct], e2A, z2[ct], code0, a.T, self_code[ct], best[ct], bidx[ct], sec[ct], psum[ct],
                                   pmin[ct], pmax[ct]);
     }
     // norms of this stage's second half, kept for the deferred scan
@@ -350,7 +395,7 @@ __global__ __launch_bounds__(512 / CT, 2 / CT) void vq_search_mfma_kernel(Search
     const int code0 = (st0 + nst - 1) * VQ_STAGE_CODES + 32;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
-      scan_tile<TEMP, PAIRWISE>(cB[ct], e2B, z2[ct], code0, a.T, self_code[ct], best[ct], bidx[ct], psum[ct],
+      scan_tile<TEMP, PAIRWISE>(cB[ct], e2B, z2[ct], code0, a.T, self_code[ct], best[ct], bidx[ct], sec[ct], psum[ct],
                                 pmin[ct], pmax[ct]);
   }
 
@@ -363,12 +408,21 @@ __global__ __launch_bounds__(512 / CT, 2 / CT) void vq_search_mfma_kernel(Search
     const float ob = __shfl_xor(b, 32);
     const int oi = __shfl_xor(bi, 32);
     const bool take = (ob < b) || (ob == b && oi < bi);
-    b = take ? ob : b;
+    bool near = false;
+    if (TEMP == VQ_T_DEFERRED) {
+      const float sc = vq_t_merge_sec(b, sec[ct], ob, __shfl_xor(sec[ct], 32));
+      const float m = take ? ob : b;
+      const float qd = m / a.T;
+      near = vq_t_near(m, sc, a.T, qd);
+      b = qd; // the winning distance as the reference reports it
+    } else {
+      b = take ? ob : b;
+    }
     bi = take ? oi : bi;
 
     const int64_t n = row0 + ct * 32 + j;
     const bool valid = n < a.N;
-    const bool finite = z2[ct] <= VQ_NORM_LIMIT &&  // false for NaN
+    const bool finite = z2[ct] <= VQ_NORM_LIMIT && !near &&  // false for NaN
                         !(a.fallback_role && valid && a.idx32[n] == -2);
     const bool ok = valid && finite;
     if (h == 0) {
@@ -383,7 +437,13 @@ __global__ __launch_bounds__(512 / CT, 2 / CT) void vq_search_mfma_kernel(Search
         if (a.idx32) a.idx32[n] = (int32_t)(bi + a.code_base);
         if (a.dmin) a.dmin[n] = b;
       } else if (valid && !a.fallback_role) {
-        a.nf_rows[atomicAdd(&a.control[VQ_CTL_NF_COUNT], 1)] = (int32_t)n;
+        if (near && a.near_ok && z2[ct] <= VQ_NORM_LIMIT) {
+          a.nf_rows[a.N - 1 - atomicAdd(&a.control[VQ_CTL_NEAR_COUNT], 1)] = (int32_t)n;
+          a.idx32[n] = 0;                   // the exact kernel's workgroups count themselves in here
+          if (a.idx64) a.idx64[n] = -1;     // ... and keep the smallest (quotient, index) key here
+        } else {
+          a.nf_rows[atomicAdd(&a.control[VQ_CTL_NF_COUNT], 1)] = (int32_t)n;
+        }
       }
     }
     if (PAIRWISE) {
@@ -594,6 +654,7 @@ __device__ __forceinline__ void half_deinterleave(f32x4& v) {
 // scalar and the lane's offset from it a constant (cyc_rsrc).
 template <int D, bool NCHW, bool TEMP, bool RESIDENT>
 __global__ __launch_bounds__(512, 2) void vq_search_cyclic_kernel(SearchArgs a, int64_t ntiles) {
+  constexpr int TMODE = TEMP ? VQ_T_DEFERRED : VQ_T_NONE;
   constexpr bool VEC = !NCHW;
   constexpr int S = D / 2;
   constexpr int G = D / 8;      // channel groups: 8 channels = 4 k-steps = one 16-byte piece of a code's image row
@@ -640,6 +701,7 @@ __global__ __launch_bounds__(512, 2) void vq_search_cyclic_kernel(SearchArgs a, 
   f32x4 gcur[PREFETCH ? U : 1];   // the winning code's values for the slice the next memory step writes
   float z2 = 0.0f;
   float best = 0.0f, best_hi = 0.0f;
+  float sec = 0.0f, sec_hi = 0.0f;   // deferred temperature: the value the running minimum displaced last
   int bidx = 0, bidx_hi = 0;
   int win = 0;               // winner of the finished tile (both lane halves hold it)
   bool okf = false;          // ... and whether this lane's row is a real, finite row
@@ -843,10 +905,11 @@ __global__ __launch_bounds__(512, 2) void vq_search_cyclic_kernel(SearchArgs a, 
         z2 = p + __shfl_xor(p, 32);  // even-channel chain + odd-channel chain
         best = __builtin_inff(); bidx = 0;
         best_hi = __builtin_inff(); bidx_hi = 0;
+        sec = __builtin_inff(); sec_hi = __builtin_inff();
       } else if (s == 0) {
         // wrapped around the end of the codebook: what was seen so far has the higher indices
-        best_hi = best; bidx_hi = bidx;
-        best = __builtin_inff(); bidx = 0;
+        best_hi = best; bidx_hi = bidx; sec_hi = sec;
+        best = __builtin_inff(); bidx = 0; sec = __builtin_inff();
       }
       f32x16 cA, cB;
       const f32x4* A = reinterpret_cast<const f32x4*>(buf) + lane;
@@ -884,28 +947,38 @@ __global__ __launch_bounds__(512, 2) void vq_search_cyclic_kernel(SearchArgs a, 
         f32x4 e2A[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) e2A[q] = e2s[2 * q];
-        scan_tile<TEMP, false>(cA, e2A, z2, s * VQ_STAGE_CODES, a.T, -1, best, bidx, pd, pf0, pf1);
+        scan_tile<TMODE, false>(cA, e2A, z2, s * VQ_STAGE_CODES, a.T, -1, best, bidx, sec, pd, pf0, pf1);
       }
       {
         f32x4 e2B[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) e2B[q] = e2s[8 + 2 * q];
-        scan_tile<TEMP, false>(cB, e2B, z2, s * VQ_STAGE_CODES + 32, a.T, -1, best, bidx, pd, pf0, pf1);
+        scan_tile<TMODE, false>(cB, e2B, z2, s * VQ_STAGE_CODES + 32, a.T, -1, best, bidx, sec, pd, pf0, pf1);
       }
 
       if (c == nst - 1) {
         // ---- the tile is swept: merge of the two runs and of the two lane halves ----------------
+        if (TEMP) sec = vq_t_merge_sec(best, sec, best_hi, sec_hi);
         if (!(best <= best_hi)) { best = best_hi; bidx = bidx_hi; }
         int bi = bidx + 4 * h;
         float b = best;
         const float ob = __shfl_xor(b, 32);
         const int oi = __shfl_xor(bi, 32);
         const bool take = (ob < b) || (ob == b && oi < bi);
-        b = take ? ob : b;
+        bool near = false;
+        if (TEMP) {
+          const float sc = vq_t_merge_sec(b, sec, ob, __shfl_xor(sec, 32));
+          const float m = take ? ob : b;
+          const float qd = m / a.T;
+          near = vq_t_near(m, sc, a.T, qd);
+          b = qd;   // the winning distance as the reference reports it
+        } else {
+          b = take ? ob : b;
+        }
         bi = take ? oi : bi;
         const int64_t n = (g + (int64_t)it * GW) * 32 + j;
         const bool valid = n < a.N;
-        okf = valid && z2 <= VQ_NORM_LIMIT;   // false for NaN
+        okf = valid && z2 <= VQ_NORM_LIMIT && !near;   // false for NaN
         win = bi;
         if (h == 0) {
           if (okf) {
@@ -913,7 +986,13 @@ __global__ __launch_bounds__(512, 2) void vq_search_cyclic_kernel(SearchArgs a, 
             if (a.idx32) a.idx32[n] = (int32_t)(bi + a.code_base);
             if (a.dmin) a.dmin[n] = b;
           } else if (valid) {
-            a.nf_rows[atomicAdd(&a.control[VQ_CTL_NF_COUNT], 1)] = (int32_t)n;
+            if (near && a.near_ok && z2 <= VQ_NORM_LIMIT) {
+              a.nf_rows[a.N - 1 - atomicAdd(&a.control[VQ_CTL_NEAR_COUNT], 1)] = (int32_t)n;
+              a.idx32[n] = 0;                   // the exact kernel's workgroups count themselves in here
+              if (a.idx64) a.idx64[n] = -1;     // ... and keep the smallest (quotient, index) key here
+            } else {
+              a.nf_rows[atomicAdd(&a.control[VQ_CTL_NF_COUNT], 1)] = (int32_t)n;
+            }
           }
         }
       }
@@ -1335,6 +1414,26 @@ __device__ __forceinline__ float z_load(const float* z, bool nchw, int64_t n, in
   return z[(b * D + c) * HW + hw];
 }
 
+__device__ __forceinline__ float search_one_row(const SearchArgs& a, int D, int nchw, int64_t n, float* zs, float* rb,
+                                                int* ri);
+__device__ __forceinline__ float row_load(const SearchArgs& a, int D, int nchw, int64_t n, float* zs, float* rb);
+__device__ __forceinline__ void row_scan(const SearchArgs& a, int D, float z2, int klo, int khi, const float* zs, float* rb,
+                                         int* ri);
+__device__ __forceinline__ float row_finish(const SearchArgs& a, int D, int nchw, int64_t n, int w, float q,
+                                            const float* zs, float* rb);
+
+// (quotient, index) as one 64-bit key whose unsigned order is "smaller quotient first, then lower index"
+__device__ __forceinline__ unsigned long long vq_row_key(float q, int idx) {
+  uint32_t u = __float_as_uint(q);
+  u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;
+  return ((unsigned long long)u << 32) | (uint32_t)idx;
+}
+__device__ __forceinline__ float vq_row_key_quotient(unsigned long long key) {
+  uint32_t u = (uint32_t)(key >> 32);
+  u ^= (u >> 31) ? 0x80000000u : 0xffffffffu;
+  return __uint_as_float(u);
+}
+
 __global__ __launch_bounds__(256) void vq_search_exact_kernel(SearchArgs a, int D, int nchw, int use_list,
                                                               float* loss_partial_out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1442,108 +1541,183 @@ __global__ __launch_bounds__(256) void vq_search_exact_kernel(SearchArgs a, int 
       if (t == 0) block_loss += rbest[0];
     }
   }
+  if (use_list) {
+    // the second list (from the end of nf_rows backwards): finite rows of a deferred-temperature sweep, one per workgroup
+    const int near = a.control[VQ_CTL_NEAR_COUNT];
+    // A short list is shared out S workgroups to a row, each taking a range of the codes: a row streams the
+    // whole codebook through one workgroup otherwise, a few hundred microseconds at 8 MiB however few the rows.
+    int S = near > 0 ? (int)gridDim.x / near : 1;
+    if (S > 8) S = 8;
+    if (S > a.K / 256) S = a.K / 256;
+    if (S < 2 || a.idx64 == nullptr) {
+      for (int i = blockIdx.x; i < near; i += gridDim.x)
+        block_loss += search_one_row(a, D, nchw, a.nf_rows[a.N - 1 - i], zs, rbest, ridx);
+    } else {
+      // near * S <= gridDim.x: at most one (row, range) per workgroup, and near <= VQ_NEAR_SLOTS
+      __shared__ int sh_last, sh_w;
+      __shared__ float sh_q;
+      const int w = blockIdx.x;
+      if (w < near * S) {
+        const int i = w / S, part = w - i * S;
+        const int64_t n = a.nf_rows[a.N - 1 - i];
+        const int Kc = ((a.K + S - 1) / S + 3) & ~3;
+        const int klo = part * Kc, khi = klo + Kc < a.K ? klo + Kc : a.K;
+        const float z2 = row_load(a, D, nchw, n, zs, rbest);
+        row_scan(a, D, z2, klo, khi, zs, rbest, ridx);
+        if (t == 0) {
+          unsigned long long* slot = reinterpret_cast<unsigned long long*>(&a.idx64[n]);
+          if (ridx[0] != 0x7fffffff) atomicMin(slot, vq_row_key(rbest[0], ridx[0]));
+          __threadfence();
+          const int ticket = atomicAdd(&a.idx32[n], 1);
+          sh_last = ticket == S - 1;
+          if (sh_last) {
+            // the last range to arrive writes the row's outputs; its loss goes to the row's own slot, so the
+            // partials do not depend on which workgroup that was
+            __threadfence();
+            const unsigned long long key = atomicMin(slot, ~0ull);
+            sh_w = (int)(uint32_t)key;
+            sh_q = vq_row_key_quotient(key);
+          }
+        }
+        __syncthreads();
+        if (sh_last) {
+          const float row_loss = row_finish(a, D, nchw, n, sh_w, sh_q, zs, rbest);
+          if (t == 0 && a.near_loss) a.near_loss[i] = row_loss;
+        }
+      }
+    }
+  }
   if (t == 0 && loss_partial_out) loss_partial_out[blockIdx.x] = block_loss;
 }
 
 // ---------------------------------------------------------------------------------------
-// One workgroup per listed row: exact fp32 distances to every code (finite rows only, D % 4 == 0,
-// D <= 1024).  Serves the few rows the filtered search cannot settle with its candidate lists;
-// the cost is ~K*D fma per row on the vector ALUs, so it only pays for short lists.
+// One workgroup, one row: exact fp32 distances to every code (finite rows only, D % 4 == 0,
+// D <= 1024), literal temperature division.  Serves short lists of rows -- those the filtered search
+// cannot settle with its candidate lists, those the deferred-temperature sweep found a code close
+// above the minimum for; the cost is ~K*D fma per row on the vector ALUs.
 // Thread t takes codes t, t + 256, ... four at a time; same fma chain as everywhere else.
+// zs: D floats (16-byte aligned), rb / ri: 256 entries each, all in LDS.  Returns (in thread 0) the
+// row's squared-difference sum when a.q_out is set.
 // ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float row_load(const SearchArgs& a, int D, int nchw, int64_t n, float* zs, float* rb) {
+  const int t = threadIdx.x;
+  __syncthreads();
+  for (int c = t; c < D; c += 256) zs[c] = z_load(a.z, nchw != 0, n, c, D, a.HW);
+  __syncthreads();
+  if (t < 2) {
+    float p = 0.0f;
+    for (int c = t; c < D; c += 2) p = __builtin_fmaf(zs[c], zs[c], p);
+    const float o = __shfl_xor(p, 1);
+    if (t == 0) rb[0] = p + o;
+  }
+  __syncthreads();
+  const float z2 = rb[0];
+  __syncthreads();
+  return z2;
+}
+
+// codes klo .. khi - 1 (klo a multiple of 4); afterwards rb[0] / ri[0] hold the smallest quotient and its lowest
+// index (0x7fffffff: the range was empty)
+__device__ __forceinline__ void row_scan(const SearchArgs& a, int D, float z2, int klo, int khi, const float* zs, float* rb,
+                                         int* ri) {
+  const int t = threadIdx.x;
+  float best = __builtin_inff();
+  int bi = 0x7fffffff;
+  for (int k0 = klo + t; k0 < khi; k0 += 1024) {
+    int kk[4];
+    const f32x4* er[4];
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      kk[q] = k0 + 256 * q;
+      er[q] = reinterpret_cast<const f32x4*>(a.E + (size_t)(kk[q] < khi ? kk[q] : k0) * D);
+    }
+#pragma unroll 4
+    for (int c4 = 0; c4 < D / 4; ++c4) {
+      const f32x4 zv = reinterpret_cast<const f32x4*>(zs)[c4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 e = er[q][c4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[q] = __builtin_fmaf(zv[m], e[m], acc[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (kk[q] < khi) {
+        float d = __builtin_fmaf(-2.0f, acc[q], z2 + a.e2[kk[q]]);
+        if (a.T != 1.0f) d = d / a.T;
+        if (d < best) { best = d; bi = kk[q]; }  // codes visited in increasing order: '<' keeps the lowest index
+      }
+    }
+  }
+  rb[t] = best;
+  ri[t] = bi;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if (t < off) {
+      const float d2 = rb[t + off];
+      const int i2 = ri[t + off];
+      if (d2 < rb[t] || (d2 == rb[t] && i2 < ri[t])) { rb[t] = d2; ri[t] = i2; }
+    }
+    __syncthreads();
+  }
+}
+
+// the row's outputs for winner w at quotient q; returns its squared-difference sum when a.q_out is set
+__device__ __forceinline__ float row_finish(const SearchArgs& a, int D, int nchw, int64_t n, int w, float q,
+                                            const float* zs, float* rb) {
+  const int t = threadIdx.x;
+  if (t == 0) {
+    if (a.idx64) a.idx64[n] = (int64_t)w + a.code_base;
+    if (a.idx32) a.idx32[n] = (int32_t)(w + a.code_base);
+    if (a.dmin) a.dmin[n] = q;
+  }
+  float row_loss = 0.0f;
+  if (a.q_out) {
+    const float* e = a.E + (size_t)w * D;
+    float part = 0.0f;
+    for (int c = t; c < D; c += 256) {
+      const float zv = zs[c];
+      const float diff = e[c] - zv;
+      part = __builtin_fmaf(diff, diff, part);
+      int64_t off;
+      if (nchw) { const int64_t b = n / a.HW, hw = n - b * a.HW; off = (b * D + c) * a.HW + hw; }
+      else off = n * D + c;
+      a.q_out[off] = zv + diff;
+    }
+    __syncthreads();
+    rb[t] = part;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+      if (t < off) rb[t] += rb[t + off];
+      __syncthreads();
+    }
+    row_loss = rb[0];
+  }
+  return row_loss;
+}
+
+__device__ __forceinline__ float search_one_row(const SearchArgs& a, int D, int nchw, int64_t n, float* zs, float* rb,
+                                                int* ri) {
+  const float z2 = row_load(a, D, nchw, n, zs, rb);
+  row_scan(a, D, z2, 0, a.K, zs, rb, ri);
+  const int w = ri[0] == 0x7fffffff ? 0 : ri[0];
+  const float q = rb[0];
+  __syncthreads();
+  return row_finish(a, D, nchw, n, w, q, zs, rb);
+}
+
 __global__ __launch_bounds__(256) void vq_search_rows_kernel(SearchArgs a, int D, int nchw,
                                                              const int32_t* __restrict__ list, int count_word,
                                                              float* __restrict__ loss_out) {
   __shared__ __attribute__((aligned(16))) float zs[1024];
   __shared__ float rb[256];
   __shared__ int ri[256];
-  __shared__ float z2s;
-  const int t = threadIdx.x;
   const int count = vq_filter_gave_up(a.control, a.N) ? 0 : a.control[count_word];
   float block_loss = 0.0f;  // meaningful in thread 0
-  for (int i = blockIdx.x; i < count; i += gridDim.x) {
-    const int64_t n = list[i];
-    __syncthreads();
-    for (int c = t; c < D; c += 256) zs[c] = z_load(a.z, nchw != 0, n, c, D, a.HW);
-    __syncthreads();
-    if (t < 2) {
-      float p = 0.0f;
-      for (int c = t; c < D; c += 2) p = __builtin_fmaf(zs[c], zs[c], p);
-      const float o = __shfl_xor(p, 1);
-      if (t == 0) z2s = p + o;
-    }
-    __syncthreads();
-    const float z2 = z2s;
-    float best = __builtin_inff();
-    int bi = 0x7fffffff;
-    for (int k0 = t; k0 < a.K; k0 += 1024) {
-      int kk[4];
-      const f32x4* er[4];
-      float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        kk[q] = k0 + 256 * q;
-        er[q] = reinterpret_cast<const f32x4*>(a.E + (size_t)(kk[q] < a.K ? kk[q] : k0) * D);
-      }
-#pragma unroll 4
-      for (int c4 = 0; c4 < D / 4; ++c4) {
-        const f32x4 zv = reinterpret_cast<const f32x4*>(zs)[c4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 e = er[q][c4];
-#pragma unroll
-          for (int m = 0; m < 4; ++m) acc[q] = __builtin_fmaf(zv[m], e[m], acc[q]);
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (kk[q] < a.K) {
-          float d = __builtin_fmaf(-2.0f, acc[q], z2 + a.e2[kk[q]]);
-          if (a.T != 1.0f) d = d / a.T;
-          if (d < best) { best = d; bi = kk[q]; }  // codes visited in increasing order: '<' keeps the lowest index
-        }
-      }
-    }
-    rb[t] = best;
-    ri[t] = bi;
-    __syncthreads();
-    for (int off = 128; off >= 1; off >>= 1) {
-      if (t < off) {
-        const float d2 = rb[t + off];
-        const int i2 = ri[t + off];
-        if (d2 < rb[t] || (d2 == rb[t] && i2 < ri[t])) { rb[t] = d2; ri[t] = i2; }
-      }
-      __syncthreads();
-    }
-    const int w = ri[0] == 0x7fffffff ? 0 : ri[0];
-    if (t == 0) {
-      if (a.idx64) a.idx64[n] = (int64_t)w + a.code_base;
-      if (a.idx32) a.idx32[n] = (int32_t)(w + a.code_base);
-      if (a.dmin) a.dmin[n] = rb[0];
-    }
-    if (a.q_out) {
-      const float* e = a.E + (size_t)w * D;
-      float part = 0.0f;
-      for (int c = t; c < D; c += 256) {
-        const float zv = zs[c];
-        const float diff = e[c] - zv;
-        part = __builtin_fmaf(diff, diff, part);
-        int64_t off;
-        if (nchw) { const int64_t b = n / a.HW, hw = n - b * a.HW; off = (b * D + c) * a.HW + hw; }
-        else off = n * D + c;
-        a.q_out[off] = zv + diff;
-      }
-      __syncthreads();
-      rb[t] = part;
-      __syncthreads();
-      for (int off = 128; off >= 1; off >>= 1) {
-        if (t < off) rb[t] += rb[t + off];
-        __syncthreads();
-      }
-      if (t == 0) block_loss += rb[0];
-    }
-  }
-  if (t == 0 && loss_out) loss_out[blockIdx.x] = block_loss;
+  for (int i = blockIdx.x; i < count; i += gridDim.x) block_loss += search_one_row(a, D, nchw, list[i], zs, rb, ri);
+  if (threadIdx.x == 0 && loss_out) loss_out[blockIdx.x] = block_loss;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1726,7 +1900,7 @@ __global__ __launch_bounds__(256) void vq_gather_st_kernel(const float* __restri
   }
 }
 
-template <int D, int CT, bool NCHW, bool TEMP, bool PAIRWISE, bool PAD = false>
+template <int D, int CT, bool NCHW, int TEMP, bool PAIRWISE, bool PAD = false>
 int launch_mfma(const SearchArgs& a, hipStream_t s) {
   constexpr int lds_bytes = (int)(2 * vq_stage_floats(D) * 4 + 256);
   auto kern = vq_search_mfma_kernel<D, CT, NCHW, TEMP, PAIRWISE, PAD>;
@@ -1744,18 +1918,24 @@ int launch_mfma(const SearchArgs& a, hipStream_t s) {
 template <int D> struct TileChoice { static constexpr int CT = 1; };
 template <> struct TileChoice<256> { static constexpr int CT = VQ_CT_256; };
 
+template <int D, int CT, bool NCHW, bool PAD>
+int dispatch_mfma_temp(const SearchArgs& a, bool temp, hipStream_t s) {
+  if (!temp) return launch_mfma<D, CT, NCHW, VQ_T_NONE, false, PAD>(a, s);
+  // partial sweeps (their winners are merged by quotient) and the filtered search's stand-in divide every distance
+  if (a.ksplit > 1 || a.fallback_role) return launch_mfma<D, CT, NCHW, VQ_T_LITERAL, false, PAD>(a, s);
+  return launch_mfma<D, CT, NCHW, VQ_T_DEFERRED, false, PAD>(a, s);
+}
+
 template <int D>
 int dispatch_mfma(const SearchArgs& a, bool nchw, bool temp, bool pairwise, hipStream_t s) {
   constexpr int CT = TileChoice<D>::CT;
   if (a.Dreal != D) {
     // fewer channels in memory than the kernel runs at: the zero-padded form (not for the pairwise sweep)
     if (pairwise || a.Dreal > D || a.Dreal <= 0) return VQ_ERR_UNSUPPORTED;
-    if (nchw) return temp ? launch_mfma<D, 1, true, true, false, true>(a, s) : launch_mfma<D, 1, true, false, false, true>(a, s);
-    return temp ? launch_mfma<D, 1, false, true, false, true>(a, s) : launch_mfma<D, 1, false, false, false, true>(a, s);
+    return nchw ? dispatch_mfma_temp<D, 1, true, true>(a, temp, s) : dispatch_mfma_temp<D, 1, false, true>(a, temp, s);
   }
-  if (pairwise) return launch_mfma<D, CT, false, false, true>(a, s);
-  if (nchw) return temp ? launch_mfma<D, CT, true, true, false>(a, s) : launch_mfma<D, CT, true, false, false>(a, s);
-  return temp ? launch_mfma<D, CT, false, true, false>(a, s) : launch_mfma<D, CT, false, false, false>(a, s);
+  if (pairwise) return launch_mfma<D, CT, false, VQ_T_NONE, true>(a, s);
+  return nchw ? dispatch_mfma_temp<D, CT, true, false>(a, temp, s) : dispatch_mfma_temp<D, CT, false, false>(a, temp, s);
 }
 
 int run_mfma(const SearchArgs& a, int D, bool nchw, bool temp, bool pairwise, hipStream_t s) {
@@ -1913,7 +2093,8 @@ size_t vq_image_bytes(int K, int D) {
 }
 size_t vq_norms_bytes(int K) { return K > 0 ? (size_t)vq_kpad(K) * 4 : 256; }
 int64_t vq_search_blocks(int64_t N) { return N > 0 ? (N + VQ_WG_ROWS - 1) / VQ_WG_ROWS : 0; }
-static int64_t loss_slots(int64_t N) { return loss_slots_for(N); }
+// (the sweep's own partials, then the VQ_NEAR_SLOTS row partials that the exact kernel's shared rows use)
+static int64_t loss_slots(int64_t N) { return loss_slots_for(N) + VQ_NEAR_SLOTS; }
 size_t vq_loss_partial_bytes(int64_t N) { return (size_t)(loss_slots(N) + VQ_FIX_WGS) * 4; }
 
 // Internal (not in the public header): knobs of the persistent short-sweep kernel, for experiments
@@ -1973,9 +2154,11 @@ static int search_common(const float* z, int layout, int64_t N, int D, int64_t H
   a.nstages = vq_kpad(K) / VQ_STAGE_CODES; a.T = temperature; a.code_base = code_base;
   a.idx64 = idx64; a.idx32 = idx32; a.dmin = dmin; a.q_out = q_out; a.loss_partial = loss_partial;
   a.nf_rows = nf_rows; a.control = control;
+  a.near_ok = (D % 4 == 0 && D <= 1024 && aligned16(E)) ? 1 : 0;   // what search_one_row takes
   const int64_t blocks = vq_search_blocks(N);
   const int64_t slots = loss_slots(N);
   a.loss_slots = slots;
+  a.near_loss = loss_partial ? loss_partial + slots - VQ_NEAR_SLOTS : nullptr;
   // T > 0 and finite keeps the MFMA path (division by it is monotone); anything else is
   // evaluated literally by the exact kernel.
   const bool t_regular = temperature > 0.0f && temperature < __builtin_inff();

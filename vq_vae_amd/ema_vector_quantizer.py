@@ -284,15 +284,17 @@ class EMAVectorQuantizer(nn.Module):
         """Counters of the most recent forward (one small device-to-host copy, i.e. a sync): rows that
         were not finite and went through the exact kernel -- the reference neither masks nor
         reports them (a NaN latent wins the argmin by torch's rule and is scattered into ema_w);
-        this module keeps that behaviour and makes it visible -- and, for the filtered search, the
-        rows its first and second pass left open."""
+        this module keeps that behaviour and makes it visible -- for a temperature other than 1, the
+        finite rows that had a code close above the minimum and were redone with every distance
+        divided, and, for the filtered search, the rows its first and second pass left open."""
         if self._ws is None or "control" not in self._ws._bufs:
-            return {"nonfinite_rows": 0, "codebook_not_finite": False, "filter_open_rows": 0, "filter_hard_rows": 0}
+            return {"nonfinite_rows": 0, "codebook_not_finite": False, "filter_open_rows": 0, "filter_hard_rows": 0,
+                    "temperature_close_rows": 0}
         # a finished step moves its counters from words 0..7 to words 8..15 and zeroes the former for the next step
         words = self._ws._bufs["control"][:64].view(torch.int32)
         c = (words[8:16] if self._ws.clean else words[:8]).cpu().tolist()
         return {"nonfinite_rows": int(c[0]), "codebook_not_finite": bool(c[1]), "filter_open_rows": int(c[4]),
-                "filter_hard_rows": int(c[5])}
+                "filter_hard_rows": int(c[5]), "temperature_close_rows": int(c[6])}
 
     # ------------------------------------------------------------------ maintenance
     # These run a few times per training run on K-sized tensors.  They keep the reference's
