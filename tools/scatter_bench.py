@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Times the EMA embedding-sum kernels at the benchmark size (K=8192, D=256, 4 Mi latents): NCHW,
-row-major by counting sort, row-major by code ranges; uniform and skewed assignments.
+row-major by counting sort, row-major by code ranges; uniform and skewed assignments.  Each form twice: called on
+its own (the launch then starts with a max|z| reduction over the latents, vq_absmax_kernel) and as inside a
+training step, where the search has left max|z| in the control block already (zmax_valid).
 
     python tools/scatter_bench.py [--rows N]
 """
@@ -46,11 +48,16 @@ def main():
         t_sorted = timed(lambda: ops.embed_sums(z_rows, idx, K, ws))
         t_ranges = timed(lambda: ops.embed_sums(z_rows, idx, K, ws, sorted_rows=False))
         t_nchw = timed(lambda: ops.embed_sums(z_nchw, idx, K, ws))
+        # the calls above left max|z| of these very latents in the control block: what a step's scatter finds
+        s_sorted = timed(lambda: ops.embed_sums(z_rows, idx, K, ws, zmax_valid=True))
+        s_nchw = timed(lambda: ops.embed_sums(z_nchw, idx, K, ws, zmax_valid=True))
         a_ = ops.embed_sums(z_rows, idx, K, ws)[0][0].clone()
         b_ = ops.reduce_slabs(ops.embed_sums(z_nchw, idx, K, ws)[0])
         err = float((a_ - b_).abs().max() / b_.abs().max())
         print(f"{name:10s} rows sorted {t_sorted:7.3f} ms ({gb / t_sorted:5.2f} TB/s)   rows by code range {t_ranges:7.3f} ms   "
-              f"NCHW {t_nchw:7.3f} ms ({gb / t_nchw:5.2f} TB/s)   sorted vs NCHW rel diff {err:.1e}", flush=True)
+              f"NCHW {t_nchw:7.3f} ms ({gb / t_nchw:5.2f} TB/s)   sorted vs NCHW rel diff {err:.1e}\n"
+              f"{'':10s} in a step (max|z| known): rows sorted {s_sorted:7.3f} ms ({gb / s_sorted:5.2f} TB/s)   "
+              f"NCHW {s_nchw:7.3f} ms ({gb / s_nchw:5.2f} TB/s)", flush=True)
 
 
 if __name__ == "__main__":
