@@ -43,7 +43,7 @@ def test_size_helpers():
     assert lib.vq_norms_bytes(100) == 128 * 4
     assert lib.vq_search_blocks(4194304) == 16384 and lib.vq_search_blocks(1) == 1
     assert lib.vq_loss_partial_bytes(4096) == (16 + 512 + 1024) * 4     # sweep, shared exact rows, exact kernel
-    assert lib.vq_scatter_slabs(4194304, 8192, 256) >= 4
+    assert lib.vq_scatter_slabs(4194304, 8192, 256) >= 2
     assert lib.vq_scatter_slabs(128, 512, 64) == 1
     # codebook split scratch: only for small batches with enough stages
     assert lib.vq_search_split_bytes(4194304, 8192) == 0 and lib.vq_search_split_bytes(8192, 64) == 0

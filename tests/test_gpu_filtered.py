@@ -199,3 +199,35 @@ def test_filtered_is_translation_invariant(dev):
     assert _same_bits(o["filtered"][2], o["fp32"][2])
     unsettled = int(o["filtered"][4][4])
     assert unsettled * 8 <= z.shape[0] * 32 * 32, unsettled      # no fall-back
+
+
+@pytest.mark.parametrize("T", [1.0, 2.5])
+def test_a_handful_of_open_rows_goes_straight_to_the_per_row_kernel(dev, T):
+    """With a codebook that has followed the data (the EMA cluster means after a training step) the first level
+    leaves a dozen rows of a 64 Ki-row batch open; at most 32 such rows skip the second level and are evaluated
+    against every code, shared out over several workgroups per row.  Same indices, distances and outputs as the
+    fp32 search, bit for bit."""
+    from vq_vae_amd import ops
+    K, D = 8192, 256
+    g = torch.Generator(device=dev).manual_seed(77)
+    z = torch.randn(64, D, 32, 32, device=dev, generator=g)
+    E = torch.randn(K, D, device=dev, generator=g)
+    w, c, u = torch.zeros(K, D, device=dev), torch.zeros(K, device=dev), torch.zeros(K, device=dev)
+    ws = ops.Workspace(dev)
+    for step in range(10):      # the codebook moves to the cluster means; the open rows dwindle
+        ops.quantize_step(z, E, w, c, u, beta=3.0, decay=0.95, epsilon=1e-5, temperature=1.0, training=True, ws=ws)
+        b = ops.search(z, E, ws, temperature=T, want_dmin=True, filtered=True)
+        ctl = b["control"].cpu().numpy()
+        if 1 <= ctl[4] <= 32:
+            break
+    assert 1 <= ctl[4] <= 32 and ctl[5] == 0, ctl[:8]      # open after the first level; the second level stood aside
+    ib, db, qb = b["indices"].clone(), b["dmin"].clone(), b["quantized"].clone()
+    lb = b["loss_partial"][: b["n_partial"]].double().sum().item()
+    assert int((b["idx32"] < 0).sum()) == 0
+    a = ops.search(z, E, ws, temperature=T, want_dmin=True, filtered=False)
+    torch.cuda.synchronize()
+    la = a["loss_partial"][: a["n_partial"]].double().sum().item()
+    assert torch.equal(a["indices"], ib)
+    assert torch.equal(a["dmin"].view(torch.int32), db.view(torch.int32))
+    assert torch.equal(a["quantized"].view(torch.int32), qb.view(torch.int32))
+    assert abs(la - lb) <= 1e-6 * abs(la)

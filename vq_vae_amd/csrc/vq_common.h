@@ -21,6 +21,9 @@ constexpr float VQ_NORM_LIMIT = 1.0e30f;
 constexpr int VQ_FIX_WGS = 1024;
 // loss partials of rows that several workgroups of the exact kernel share (one slot per row)
 constexpr int VQ_NEAR_SLOTS = VQ_FIX_WGS / 2;
+// filtered search: with at most this many rows left open by the first level, the second level is skipped and
+// the per-row kernel takes them directly
+constexpr int VQ_FILTER_FEW_ROWS = 32;
 
 __host__ __device__ inline int vq_kpad(int K) { return (K + VQ_STAGE_CODES - 1) / VQ_STAGE_CODES * VQ_STAGE_CODES; }
 // One stage of the codebook image: 64 codes x D floats in MFMA-fragment order, then the
@@ -152,4 +155,5 @@ bool vq_filter_supported(int K, int D);
 extern "C" int vq_filter_verify_launch(const float* z, int nchw, int64_t N, int D, int64_t HW, const float* E,
                                        const float* e2, const void* fimage, int K, float T, int64_t code_base,
                                        int64_t* idx64, int32_t* idx32, float* dmin, int32_t* nf_rows,
-                                       int32_t** hard_rows_out, int32_t* control, void* work, void* stream);
+                                       int32_t** open_rows_out, int32_t** hard_rows_out, int32_t* control, void* work,
+                                       void* stream);

@@ -71,10 +71,15 @@ constexpr int SCAT_THREADS = 512;
 
 struct ScatterPlan { int nslab; int64_t rows_per_slab; };
 
+// Workgroups a launch aims at: one per CU (a workgroup's accumulators take 128 KiB of LDS, so a CU holds one anyway).
+// Every slab costs each of its workgroups an LDS clear and a flush of its K x 2 sums, whatever the batch: with 512
+// workgroups (4 slabs at D = 256) a 64 Ki-row batch took 78 us, with 256 (2 slabs) 53 us; 4 Mi rows 0.93 ms either way.
+int g_scatter_wgs = 256;   // (vq_internal_scatter_wgs changes it: experiments)
+
 ScatterPlan scatter_plan(int64_t N, int K, int D) {
   const int slices = (D + 1) / 2;
   const int kr = (K + SCAT_KR - 1) / SCAT_KR;
-  int64_t want = (512 + (int64_t)slices * kr - 1) / ((int64_t)slices * kr);  // >= 512 workgroups in all
+  int64_t want = (g_scatter_wgs + (int64_t)slices * kr - 1) / ((int64_t)slices * kr);  // that many workgroups in all
   const int64_t maxslab = (N + SCAT_MIN_ROWS - 1) / SCAT_MIN_ROWS;
   if (want > maxslab) want = maxslab;
   if (want < 1) want = 1;
@@ -712,6 +717,8 @@ int vq_scatter_slabs(int64_t N, int K, int D) {
   if (N <= 0 || K <= 0 || D <= 0) return 0;
   return scatter_plan(N, K, D).nslab;
 }
+
+int vq_internal_scatter_wgs(int v) { const int old = g_scatter_wgs; g_scatter_wgs = v; return old; }
 
 int vq_scatter_slabs_for(int64_t N, int K, int D, int layout, int64_t HW) {
   if (N <= 0 || K <= 0 || D <= 0) return 0;

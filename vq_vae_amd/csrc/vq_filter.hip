@@ -76,14 +76,23 @@ __host__ __device__ inline int fq_tiles(int K) { return (K + 32 * FQ_STAGE_TILES
 // leaves its own key lists and vqf_merge_kernel folds them into the lists an undivided sweep would
 // have produced.  Evaluated on the host (first pass: the row count is known) and on the device
 // (second pass: the row count is a counter in device memory) with the same result.
-constexpr int FQ_MAX_SPLIT = 8;
+constexpr int FQ_MAX_SPLIT = 8;          // first pass: the work buffer holds up to this many key lists per row
+#ifndef FQ_LIST_SPLIT
+#define FQ_LIST_SPLIT 16   // measured at 64 Ki rows: 8 parts 0.549 / 0.664 ms per training / eval step, 16: 0.528 / 0.642, 32: 0.546 / 0.728
+#endif
+constexpr int FQ_MAX_SPLIT_LIST = FQ_LIST_SPLIT;    // second pass (a list of rows): rows x parts must stay within N lists
 // parts wanted for a launch of `wgs` row workgroups, before the codebook's size limits it
-__host__ __device__ inline int fq_split_wanted(int64_t wgs) {
+__host__ __device__ inline int fq_split_wanted(int64_t wgs, int cap = FQ_MAX_SPLIT) {
   const int s = wgs >= 192 ? 1 : (int)(256 / (wgs > 0 ? wgs : 1));
-  return s > FQ_MAX_SPLIT ? FQ_MAX_SPLIT : s;
+  return s > cap ? cap : s;
 }
-__host__ __device__ inline void fq_split(int64_t wgs, int nstages, int& S, int& sps) {
-  int s = fq_split_wanted(wgs);
+// the second pass's limit: its lists live in a region sized for N of them, and at most N/8 rows reach it
+__host__ __device__ inline int fq_list_cap(int64_t nrows, int64_t N) {
+  const int64_t c = nrows > 0 ? N / nrows : FQ_MAX_SPLIT_LIST;
+  return c > FQ_MAX_SPLIT_LIST ? FQ_MAX_SPLIT_LIST : (c < 1 ? 1 : (int)c);
+}
+__host__ __device__ inline void fq_split(int64_t wgs, int nstages, int& S, int& sps, int cap = FQ_MAX_SPLIT) {
+  int s = fq_split_wanted(wgs, cap);
   if (s > nstages / 2) s = nstages / 2;
   if (s < 1) s = 1;
   sps = (nstages + s - 1) / s;
@@ -268,10 +277,11 @@ __global__ __launch_bounds__(512, 2) void vqf_filter_kernel(FilterArgs a) {
   if (listed) {
     nrows = a.control[a.count_word];
     if (nrows * 8 > a.N) return;  // too many unsettled rows: the fp32 kernel redoes the batch
+    if (nrows <= VQ_FILTER_FEW_ROWS) return;  // a handful: the per-row kernel takes them directly
   }
   if ((int64_t)blockIdx.x * FQ_WG_ROWS >= nrows) return;  // list mode: the grid covers the worst case
   int nsplit, sps;
-  fq_split((nrows + FQ_WG_ROWS - 1) / FQ_WG_ROWS, a.nstages, nsplit, sps);
+  fq_split((nrows + FQ_WG_ROWS - 1) / FQ_WG_ROWS, a.nstages, nsplit, sps, listed ? fq_list_cap(nrows, a.N) : FQ_MAX_SPLIT);
   const int part = blockIdx.y;
   if (part >= nsplit) return;
   const int st_begin = part * sps;
@@ -447,11 +457,11 @@ __global__ __launch_bounds__(256) void vqf_merge_kernel(const u32x4* __restrict_
   int64_t nrows = N;
   if (count_word >= 0) {
     nrows = control[count_word];
-    if (nrows * 8 > N) return;
+    if (nrows * 8 > N || nrows <= VQ_FILTER_FEW_ROWS) return;
   }
   if (control[VQ_CTL_CB_FLAG] != 0 || pos >= nrows) return;
   int nsplit, sps;
-  fq_split((nrows + FQ_WG_ROWS - 1) / FQ_WG_ROWS, nstages, nsplit, sps);
+  fq_split((nrows + FQ_WG_ROWS - 1) / FQ_WG_ROWS, nstages, nsplit, sps, count_word >= 0 ? fq_list_cap(nrows, N) : FQ_MAX_SPLIT);
   uint32_t m[R];
 #pragma unroll
   for (int i = 0; i < R; ++i) m[i] = 0x7f800000u;
@@ -514,6 +524,7 @@ __global__ __launch_bounds__(256) void vqf_verify_kernel(VerifyArgs a) {
   const int64_t pos = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const bool listed = a.row_list != nullptr;
   if (listed && (int64_t)a.control[a.count_word] * 8 > a.N) return;  // the fp32 kernel redoes the batch
+  if (listed && a.control[a.count_word] <= VQ_FILTER_FEW_ROWS) return;  // a handful: the per-row kernel takes them directly
   if (pos >= (listed ? (int64_t)a.control[a.count_word] : a.N)) return;
   const int64_t n = listed ? (int64_t)a.row_list[pos] : pos;
   bool exact_row = a.control[VQ_CTL_CB_FLAG] != 0;
@@ -657,7 +668,7 @@ int launch_filter(const FilterArgs& a, hipStream_t s) {
   const int64_t rows = a.row_list ? (a.N + 7) / 8 : a.N;
   const int64_t blocks = (rows + FQ_WG_ROWS - 1) / FQ_WG_ROWS;
   int nsplit = 1, sps = a.nstages;
-  if (a.row_list) nsplit = a.nstages / 2 < FQ_MAX_SPLIT ? (a.nstages / 2 > 0 ? a.nstages / 2 : 1) : FQ_MAX_SPLIT;
+  if (a.row_list) nsplit = a.nstages / 2 < FQ_MAX_SPLIT_LIST ? (a.nstages / 2 > 0 ? a.nstages / 2 : 1) : FQ_MAX_SPLIT_LIST;
   else fq_split(blocks, a.nstages, nsplit, sps);
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)nsplit), dim3(512), lds_bytes, s, a);
   return vq_hip_status(hipGetLastError());
@@ -753,14 +764,15 @@ size_t vq_filter_work_bytes(int64_t N) {
 // in *hard_rows_out (control[VQ_CTL_OVF2_COUNT]) for the per-row kernel.  Unsettled rows hold -1.
 int vq_filter_verify_launch(const float* z, int nchw, int64_t N, int D, int64_t HW, const float* E, const float* e2,
                             const void* fimage, int K, float T, int64_t code_base, int64_t* idx64, int32_t* idx32,
-                            float* dmin, int32_t* nf_rows, int32_t** hard_rows_out, int32_t* control, void* work,
-                            void* stream) {
+                            float* dmin, int32_t* nf_rows, int32_t** open_rows_out, int32_t** hard_rows_out,
+                            int32_t* control, void* work, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const int tiles = fq_tiles(K);
   char* w = static_cast<char*>(work);
   const size_t NP = (size_t)((N + 3) & ~(int64_t)3);   // region stride: keeps every region 16-byte aligned
   int32_t* listA = reinterpret_cast<int32_t*>(w + NP * 64);
   int32_t* listB = reinterpret_cast<int32_t*>(w + NP * 164);
+  *open_rows_out = listA;
   *hard_rows_out = listB;
   FilterArgs f{};
   f.z = z; f.image = static_cast<const u32x4*>(fimage);

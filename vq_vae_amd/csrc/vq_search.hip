@@ -1434,6 +1434,10 @@ __device__ __forceinline__ float vq_row_key_quotient(unsigned long long key) {
   return __uint_as_float(u);
 }
 
+__device__ __forceinline__ float search_listed_rows(const SearchArgs& a, int D, int nchw, const int32_t* list, int list_step,
+                                                    int count, int ticket_base, float* row_loss_slots, float* zs, float* rb,
+                                                    int* ri);
+
 __global__ __launch_bounds__(256) void vq_search_exact_kernel(SearchArgs a, int D, int nchw, int use_list,
                                                               float* loss_partial_out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1544,48 +1548,7 @@ __global__ __launch_bounds__(256) void vq_search_exact_kernel(SearchArgs a, int 
   if (use_list) {
     // the second list (from the end of nf_rows backwards): finite rows of a deferred-temperature sweep, one per workgroup
     const int near = a.control[VQ_CTL_NEAR_COUNT];
-    // A short list is shared out S workgroups to a row, each taking a range of the codes: a row streams the
-    // whole codebook through one workgroup otherwise, a few hundred microseconds at 8 MiB however few the rows.
-    int S = near > 0 ? (int)gridDim.x / near : 1;
-    if (S > 8) S = 8;
-    if (S > a.K / 256) S = a.K / 256;
-    if (S < 2 || a.idx64 == nullptr) {
-      for (int i = blockIdx.x; i < near; i += gridDim.x)
-        block_loss += search_one_row(a, D, nchw, a.nf_rows[a.N - 1 - i], zs, rbest, ridx);
-    } else {
-      // near * S <= gridDim.x: at most one (row, range) per workgroup, and near <= VQ_NEAR_SLOTS
-      __shared__ int sh_last, sh_w;
-      __shared__ float sh_q;
-      const int w = blockIdx.x;
-      if (w < near * S) {
-        const int i = w / S, part = w - i * S;
-        const int64_t n = a.nf_rows[a.N - 1 - i];
-        const int Kc = ((a.K + S - 1) / S + 3) & ~3;
-        const int klo = part * Kc, khi = klo + Kc < a.K ? klo + Kc : a.K;
-        const float z2 = row_load(a, D, nchw, n, zs, rbest);
-        row_scan(a, D, z2, klo, khi, zs, rbest, ridx);
-        if (t == 0) {
-          unsigned long long* slot = reinterpret_cast<unsigned long long*>(&a.idx64[n]);
-          if (ridx[0] != 0x7fffffff) atomicMin(slot, vq_row_key(rbest[0], ridx[0]));
-          __threadfence();
-          const int ticket = atomicAdd(&a.idx32[n], 1);
-          sh_last = ticket == S - 1;
-          if (sh_last) {
-            // the last range to arrive writes the row's outputs; its loss goes to the row's own slot, so the
-            // partials do not depend on which workgroup that was
-            __threadfence();
-            const unsigned long long key = atomicMin(slot, ~0ull);
-            sh_w = (int)(uint32_t)key;
-            sh_q = vq_row_key_quotient(key);
-          }
-        }
-        __syncthreads();
-        if (sh_last) {
-          const float row_loss = row_finish(a, D, nchw, n, sh_w, sh_q, zs, rbest);
-          if (t == 0 && a.near_loss) a.near_loss[i] = row_loss;
-        }
-      }
-    }
+    block_loss += search_listed_rows(a, D, nchw, a.nf_rows + (a.N - 1), -1, near, 0, a.near_loss, zs, rbest, ridx);
   }
   if (t == 0 && loss_partial_out) loss_partial_out[blockIdx.x] = block_loss;
 }
@@ -1708,15 +1671,79 @@ __device__ __forceinline__ float search_one_row(const SearchArgs& a, int D, int 
   return row_finish(a, D, nchw, n, w, q, zs, rb);
 }
 
+// A list of rows (entry i at list[i * list_step]) through search_one_row.  A short list is shared out S <= 8
+// workgroups to a row, each taking a range of the codes -- a row streams the whole codebook through one workgroup
+// otherwise, a few hundred microseconds at 8 MiB however few the rows: the ranges fold their (quotient, index)
+// winners with a 64-bit atomicMin in the row's idx64 slot (which must hold -1), count themselves in the row's idx32
+// slot (which must hold ticket_base), and the last to arrive writes the row's outputs.  Its loss goes to
+// row_loss_slots[i] when given (so that the partials do not depend on which workgroup that was), else into the
+// return value, as do the losses of rows that one workgroup handled alone (meaningful in thread 0).
+__device__ __forceinline__ float search_listed_rows(const SearchArgs& a, int D, int nchw, const int32_t* list, int list_step,
+                                                    int count, int ticket_base, float* row_loss_slots, float* zs, float* rb,
+                                                    int* ri) {
+  float block_loss = 0.0f;
+  int S = count > 0 ? (int)gridDim.x / count : 1;
+  if (S > 8) S = 8;
+  if (S > a.K / 256) S = a.K / 256;
+  if (S < 2 || a.idx64 == nullptr) {
+    for (int i = blockIdx.x; i < count; i += gridDim.x)
+      block_loss += search_one_row(a, D, nchw, list[(int64_t)i * list_step], zs, rb, ri);
+    return block_loss;
+  }
+  // count * S <= gridDim.x: at most one (row, range) per workgroup
+  __shared__ int sh_last, sh_w;
+  __shared__ float sh_q;
+  const int w = blockIdx.x;
+  if (w >= count * S) return 0.0f;
+  const int i = w / S, part = w - i * S;
+  const int64_t n = list[(int64_t)i * list_step];
+  const int Kc = ((a.K + S - 1) / S + 3) & ~3;
+  const int klo = part * Kc, khi = klo + Kc < a.K ? klo + Kc : a.K;
+  const float z2 = row_load(a, D, nchw, n, zs, rb);
+  row_scan(a, D, z2, klo, khi, zs, rb, ri);
+  if (threadIdx.x == 0) {
+    unsigned long long* slot = reinterpret_cast<unsigned long long*>(&a.idx64[n]);
+    if (ri[0] != 0x7fffffff) atomicMin(slot, vq_row_key(rb[0], ri[0]));
+    __threadfence();
+    const int ticket = atomicAdd(&a.idx32[n], 1);
+    sh_last = ticket == ticket_base + S - 1;
+    if (sh_last) {
+      __threadfence();
+      const unsigned long long key = atomicMin(slot, ~0ull);
+      sh_w = (int)(uint32_t)key;
+      sh_q = vq_row_key_quotient(key);
+    }
+  }
+  __syncthreads();
+  if (sh_last) {
+    const float row_loss = row_finish(a, D, nchw, n, sh_w, sh_q, zs, rb);
+    if (row_loss_slots) {
+      if (threadIdx.x == 0) row_loss_slots[i] = row_loss;
+    } else {
+      block_loss = row_loss;
+    }
+  }
+  return block_loss;
+}
+
+// The filtered search's last resort: the rows that both of its levels left open (list_b, counted in
+// control[word_b]) -- or, when the first level left only a handful open (at most VQ_FILTER_FEW_ROWS, list_a /
+// word_a), those rows directly: the second level's three launches then return at once, and their fixed cost
+// (0.1 ms for a dozen rows) is spared.
 __global__ __launch_bounds__(256) void vq_search_rows_kernel(SearchArgs a, int D, int nchw,
-                                                             const int32_t* __restrict__ list, int count_word,
+                                                             const int32_t* __restrict__ list_a, int word_a,
+                                                             const int32_t* __restrict__ list_b, int word_b,
                                                              float* __restrict__ loss_out) {
   __shared__ __attribute__((aligned(16))) float zs[1024];
   __shared__ float rb[256];
   __shared__ int ri[256];
-  const int count = vq_filter_gave_up(a.control, a.N) ? 0 : a.control[count_word];
   float block_loss = 0.0f;  // meaningful in thread 0
-  for (int i = blockIdx.x; i < count; i += gridDim.x) block_loss += search_one_row(a, D, nchw, list[i], zs, rb, ri);
+  if (!vq_filter_gave_up(a.control, a.N)) {
+    const int ca = a.control[word_a];
+    const bool few = ca <= VQ_FILTER_FEW_ROWS;
+    // (rows of either list hold -1 in idx32 and idx64: the marks the verification left)
+    block_loss = search_listed_rows(a, D, nchw, few ? list_a : list_b, 1, few ? ca : a.control[word_b], -1, nullptr, zs, rb, ri);
+  }
   if (threadIdx.x == 0 && loss_out) loss_out[blockIdx.x] = block_loss;
 }
 
@@ -2246,8 +2273,9 @@ int vq_search_filtered(const float* z, int layout, int64_t N, int D, int64_t HW,
   const int64_t blocks = vq_search_blocks(N);
   // 1. bf16 filter + exact verification of the candidates, two levels: settles almost every row
   int32_t* hard_rows = nullptr;
+  int32_t* open_rows = nullptr;   // what the first level left open (the second level's input)
   int rc = vq_filter_verify_launch(z, nchw ? 1 : 0, N, D, HW, E, e2, fimage, K, temperature, code_base, idx64, idx32,
-                                   dmin, nf_rows, &hard_rows, control, work, stream);
+                                   dmin, nf_rows, &open_rows, &hard_rows, control, work, stream);
   if (rc != VQ_OK) return rc;
   if (q_out) {
     // 2. settled rows: gather + straight-through + loss partials (rows marked -1 are skipped)
@@ -2260,10 +2288,12 @@ int vq_search_filtered(const float* z, int layout, int64_t N, int D, int64_t HW,
   a.nstages = vq_kpad(K) / VQ_STAGE_CODES; a.T = temperature; a.code_base = code_base;
   a.idx64 = idx64; a.idx32 = idx32; a.dmin = dmin; a.q_out = q_out;
   a.nf_rows = nf_rows; a.control = control; a.ksplit = 1; a.stages_per_split = a.nstages;
-  // 3. the few rows with more close codes than both candidate lists hold: one workgroup per row
+  // 3. the few rows with more close codes than both candidate lists hold (or the handful the first level left
+  //    open, when the second level stood aside): every code for each of them
   float* row_loss = loss_partial ? loss_partial + 2 * blocks + VQ_FIX_WGS : nullptr;
   hipLaunchKernelGGL(vq_search_rows_kernel, dim3(VQ_FIX_WGS), dim3(256), 0, s, a, D, nchw ? 1 : 0,
-                     (const int32_t*)hard_rows, (int)VQ_CTL_OVF2_COUNT, row_loss);
+                     (const int32_t*)open_rows, (int)VQ_CTL_OVF_COUNT, (const int32_t*)hard_rows, (int)VQ_CTL_OVF2_COUNT,
+                     row_loss);
   VQ_CHECK_HIP(hipGetLastError());
   // 4. fall-back: a batch the filter could not separate (over N/8 rows unsettled after the first
   //    pass) is redone by the fp32 kernel; otherwise its workgroups exit at once
