@@ -134,7 +134,7 @@ def parity_gate(zs: torch.Tensor, E0: torch.Tensor, dense_idx=None) -> dict:
                        f"{idx.size / t_cpu:.0f} vectors/s ({t_cpu:.2f} s for the sample)"}
 
 
-def measured_traffic(rows: int):
+def measured_traffic(rows: int, kernel_prefix: str):
     """HBM bytes per launch of the search kernel from the committed rocprofv3 PMC passes
     (profiles/r*_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction).  bench.py cannot
     collect PMC counters itself, so the figure is only quoted when the profile was taken on this workload
@@ -156,7 +156,7 @@ def measured_traffic(rows: int):
             if prof.get("source_sha256", {}).get("vq_vae_amd/csrc/vq_search.hip") != sha:
                 continue
             for k in prof["kernels"]:
-                if k["kernel"].startswith("vq_search_mfma_kernel"):
+                if k["kernel"].startswith(kernel_prefix):
                     return float(k["hbm_bytes_corrected"]), os.path.relpath(path, ROOT)
         except (OSError, KeyError, ValueError):
             continue
@@ -212,7 +212,7 @@ def main() -> None:
     dev = torch.device("cuda", local_rank)
 
     import torch.distributed as dist
-    from vq_vae_amd import ops
+    from vq_vae_amd import _lib, ops
     from vq_vae_amd.distributed import make_stats_reduce
 
     stats_reduce = None
@@ -344,7 +344,10 @@ def main() -> None:
             small = {"error": f"{type(exc).__name__}: {exc}"}
 
     if rank == 0:
-        traffic, traffic_src = measured_traffic(rows)
+        # which of the library's two matrix-core kernels the search ran for this batch (same results either way)
+        persistent = bool(_lib.load().vq_search_uses_persistent_kernel(rows, K, D, 1, H * W))
+        kernel_name = "vq_search_cyclic_kernel" if persistent else "vq_search_mfma_kernel"
+        traffic, traffic_src = measured_traffic(rows, kernel_name)
         ms_per_step = elapsed / args.steps * 1e3
         line = {
             "metric": "quantized latent vectors/sec (argmin+EMA update), K=8192 D=256",
@@ -366,7 +369,7 @@ def main() -> None:
                                    + ("N(0,1) codebook" if args.codebook == "normal" else "U(-1/K,1/K) codebook (skewed)")
                                    + f", decay {DECAY}",
                        "rows_per_gpu": rows, "parallelism": f"dp{world}" if world > 1 else "single"},
-            "roofline": {"bound": "mfma", "kernel": "vq_search_mfma_kernel<256,NCHW>", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": f"{kernel_name}<{D},NCHW>", "achieved": achieved,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "traffic": traffic, "traffic_unit": "bytes/launch (rocprofv3 PMC)", "traffic_source": traffic_src,
                          "algorithmic_hbm_bytes": rows * (2 * D * 4 + 12), "ms_per_launch": search_ms,

@@ -61,6 +61,11 @@ size_t vq_image_bytes(int K, int D);            /* codebook image, the search's 
 size_t vq_norms_bytes(int K);                   /* squared norms of the (padded) codebook          */
 int64_t vq_search_blocks(int64_t N);            /* workgroups of vq_search = loss partials it writes*/
 size_t vq_loss_partial_bytes(int64_t N);        /* floats: the sweep's partials + the exact kernel's */
+/* Which of its two matrix-core kernels vq_search runs for this problem (both give the same bits): 1 = the
+ * persistent kernel (large batches; every codebook size at D >= 128, up to 1024 codes below), 0 = one workgroup
+ * per 256 rows (small batches, divided sweeps, zero-padded channel counts).  Host-side rule only; for profiles and
+ * benchmarks that have to name the kernel they measure.  No counterpart in the reference. */
+int vq_search_uses_persistent_kernel(int64_t N, int K, int D, int layout, int64_t HW);
 size_t vq_control_bytes(void);                  /* small block of control words                    */
 size_t vq_search_split_bytes(int64_t N, int K); /* scratch of the codebook split (0: this N, K is not split) */
 int vq_scatter_slabs(int64_t N, int K, int D);  /* number of partial-sum slabs vq_ema_scatter writes (NCHW)*/

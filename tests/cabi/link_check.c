@@ -24,6 +24,8 @@ int main(void) {
   CHECK(vq_norms_bytes(8192) == 8192 * 4);
   CHECK(vq_search_blocks(4194304) == 16384);
   CHECK(vq_loss_partial_bytes(4194304) >= (size_t)16384 * 4);
+  CHECK(vq_search_uses_persistent_kernel(4194304, 8192, 256, VQ_LAYOUT_NCHW, 1024) == 1);
+  CHECK(vq_search_uses_persistent_kernel(4096, 512, 64, VQ_LAYOUT_NCHW, 256) == 0);
   CHECK(vq_control_bytes() >= 16 * 4);
   CHECK(vq_filter_work_bytes(4194304) == (size_t)4194304 * 168);
   CHECK(vq_filter_image_bytes(8192, 256) > (size_t)8192 * 256 * 2);

@@ -43,6 +43,12 @@ def test_size_helpers():
     assert lib.vq_norms_bytes(100) == 128 * 4
     assert lib.vq_search_blocks(4194304) == 16384 and lib.vq_search_blocks(1) == 1
     assert lib.vq_loss_partial_bytes(4096) == (16 + 512 + 1024) * 4     # sweep, shared exact rows, exact kernel
+    # the persistent kernel: large batches; every codebook size from 128 channels up, K <= 1024 below; not zero-padded counts
+    assert lib.vq_search_uses_persistent_kernel(4194304, 8192, 256, 1, 1024) == 1
+    assert lib.vq_search_uses_persistent_kernel(4194304, 8192, 64, 1, 1024) == 0
+    assert lib.vq_search_uses_persistent_kernel(1048576, 512, 64, 0, 1) == 1
+    assert lib.vq_search_uses_persistent_kernel(1048576, 1000, 48, 1, 1024) == 0
+    assert lib.vq_search_uses_persistent_kernel(65536, 8192, 256, 1, 1024) == 0
     assert lib.vq_scatter_slabs(4194304, 8192, 256) >= 2
     assert lib.vq_scatter_slabs(128, 512, 64) == 1
     # codebook split scratch: only for small batches with enough stages

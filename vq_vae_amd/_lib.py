@@ -25,6 +25,7 @@ SIGNATURES = {
     "vq_norms_bytes": (c_size_t, [c_int]),
     "vq_search_blocks": (c_int64, [c_int64]),
     "vq_loss_partial_bytes": (c_size_t, [c_int64]),
+    "vq_search_uses_persistent_kernel": (c_int, [c_int64, c_int, c_int, c_int, c_int64]),
     "vq_control_bytes": (c_size_t, []),
     "vq_search_split_bytes": (c_size_t, [c_int64, c_int]),
     "vq_scatter_slabs": (c_int, [c_int64, c_int, c_int]),

@@ -104,6 +104,38 @@ __device__ __forceinline__ void stage_copy(const float* image, int stage, float*
   }
 }
 
+// The same copy addressed through a buffer descriptor over the image: a wave takes a contiguous run of the
+// stage's pieces, so that a piece is "descriptor + scalar offset + immediate (0 / 1 / 2 / 3 KiB) + lane x 16" on
+// the memory side and "M0 + the same immediate + lane x 16" on the LDS side -- a DMA instruction needs no vector
+// instruction beside it (the pointer form spends a 64-bit vector add per piece, and the piece addresses, hoisted
+// out of the stage loop, live in scalar registers that spill), only two scalar adds per four pieces.  Vector
+// instructions are what a loader wave must not spend: they issue in the gaps of its SIMD partner's MFMAs.
+template <int IMM>
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, float* l, uint32_t voff, uint32_t soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)l, 16, voff, soff, IMM, 0);
+}
+template <int I, int N>
+__device__ __forceinline__ void dma_run(__amdgpu_buffer_rsrc_t r, float* l, uint32_t voff, uint32_t soff, int count) {
+  if constexpr (I < N) {
+    if (I < count) dma16<(I % 4) * 1024>(r, l + (I / 4) * 1024, voff, soff + (I / 4) * 4096);
+    dma_run<I + 1, N>(r, l, voff, soff, count);
+  }
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t image_rsrc(const float* image, int nstages, int D) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(image), 0, (int)((size_t)nstages * vq_stage_floats(D) * 4), 0x00020000);
+}
+template <int D, int NW>
+__device__ __forceinline__ void stage_copy_buf(__amdgpu_buffer_rsrc_t r, int stage, float* lds_buf, int wave, int lane) {
+  constexpr int NL = NW == 8 ? 4 : NW;  // loader waves (see stage_copy)
+  constexpr int PIECES = D / 4 + 1;
+  constexpr int PER = (PIECES + NL - 1) / NL;
+  if (wave >= NL) return;
+  const int first = wave * PER;
+  const int count = PIECES - first < PER ? PIECES - first : PER;
+  dma_run<0, PER>(r, lds_buf + first * 256, (uint32_t)lane * 16u, (uint32_t)stage * (uint32_t)(vq_stage_floats(D) * 4) + (uint32_t)first * 1024u,
+                  count);
+}
+
 // Scan one finished 32-code x 32-latent accumulator tile.  Register r of the tile is code
 // row (r&3) + 8*(r>>2) + 4*(lane>>5); the 4*(lane>>5) part is added once after the sweep.
 //
@@ -220,7 +252,8 @@ __global__ __launch_bounds__(512 / CT, 2 / CT) void vq_search_mfma_kernel(Search
   }
 
   // Prologue DMA of stage 0 goes out first; it lands while z is being loaded.
-  stage_copy<D, NW>(image, 0, lds, wave, lane);
+  const __amdgpu_buffer_rsrc_t img = image_rsrc(image, nst, D);
+  stage_copy_buf<D, NW>(img, 0, lds, wave, lane);
 
   // ---- z tile into registers, in B-operand order: zr[ct][s] = z[row][2s + h] -----------
   float zr[CT][S];
@@ -324,7 +357,7 @@ __global__ __launch_bounds__(512 / CT, 2 / CT) void vq_search_mfma_kernel(Search
   int cur = 0;
   for (int st = 0; st < nst; ++st) {
     float* buf = lds + cur * STAGE_F;
-    if (st + 1 < nst) stage_copy<D, NW>(image, st + 1, lds + (cur ^ 1) * STAGE_F, wave, lane);
+    if (st + 1 < nst) stage_copy_buf<D, NW>(img, st + 1, lds + (cur ^ 1) * STAGE_F, wave, lane);
 
     const f32x4* A = reinterpret_cast<const f32x4*>(buf) + lane;
     const f32x4* e2s = reinterpret_cast<const f32x4*>(buf + VQ_STAGE_CODES * D) + h;
@@ -846,7 +879,7 @@ __global__ __launch_bounds__(512, 2) void vq_search_cyclic_kernel(SearchArgs a, 
   const float* buf = lds;
   auto dma_issue = [&]() __attribute__((always_inline)) {
     if (!RESIDENT && issuer && k + 1 < kend)
-      cyc_stage_copy<D>(a.image, s + 1 == nst ? 0 : s + 1, lds + (size_t)((k + 1) & 1) * STAGE_F, wave & 3, 4, lane);
+      stage_copy_buf<D, 8>(irsrc, s + 1 == nst ? 0 : s + 1, lds + (size_t)((k + 1) & 1) * STAGE_F, wave & 3, lane);
   };
   // defer_dma: the caller issues the DMA itself, later in the step (a sweeping wave does so between its
   // two halves: at the start of a step the memory-step waves send their loads and stores, and a DMA
@@ -1986,7 +2019,7 @@ int64_t loss_slots_for(int64_t N) {
 // ---- the persistent kernel for short sweeps: when it runs, and how ---------------------------
 struct CyclicTune {
   int enable = 1;
-  int max_stages = 16;          // K <= 1024: beyond that the one-tile-per-workgroup kernel is as fast
+  int max_stages = 16;          // fewer than 128 channels: K <= 1024, beyond that the one-tile-per-workgroup kernel is as fast
   int64_t min_tiles_per_wave = 2;
   int force_streaming = 0;      // never keep the image resident (experiments)
 };
@@ -2011,7 +2044,10 @@ bool cyc_eligible(int64_t N, int K, int D, bool nchw, int64_t HW) {
   if (nchw && HW % 32 != 0) return false;      // a 32-row tile must lie inside one image
   if (loss_slots_for(N) < VQ_CYC_WAVES) return false;   // one loss partial per wave of the grid
   const int nstages = vq_kpad(K) / VQ_STAGE_CODES;
-  if (nstages > g_cyc.max_stages) return false;
+  // long sweeps: with at least 128 channels the persistent kernel is ahead at every codebook size (K = 8192, D = 256,
+  // 4 Mi rows: 122.3 against 123.6 ms; D = 128: 64.0 against 64.9 ms), with 64 channels only up to 16 stages
+  // (K = 8192, D = 64: 35.1 against 33.1 ms)
+  if (D < 128 && nstages > g_cyc.max_stages) return false;
   const int64_t ntiles = (N + 31) / 32;
   if (ntiles < g_cyc.min_tiles_per_wave * VQ_CYC_WAVES) return false;
   // cycling stages: the two groups' memory steps must not overlap, or nobody is left to issue the DMA
@@ -2138,6 +2174,14 @@ int vq_internal_tune(int what, int value) {
   return old;
 }
 size_t vq_control_bytes(void) { return VQ_CTL_WORDS * 4; }
+
+int vq_search_uses_persistent_kernel(int64_t N, int K, int D, int layout, int64_t HW) {
+  if (N <= 0 || K <= 0 || D <= 0 || vq_pad_dim(D) != D) return 0;
+  const bool nchw = layout == VQ_LAYOUT_NCHW;
+  const SplitPlan sp = split_plan(N, K);
+  if (sp.ksplit > 1) return 0;   // (a caller that passes no split workspace gets the undivided sweep instead)
+  return cyc_eligible(N, K, D, nchw, nchw ? HW : 1) ? 1 : 0;
+}
 
 int vq_control_reset(int32_t* control, void* stream) {
   if (!control) return VQ_ERR_INVALID_ARG;
