@@ -506,3 +506,115 @@ def test_deferred_temperature_on_large_batches(images, K, D, rows_layout, dev, o
         if K >= 512:
             # each such row has a partial of its own whatever workgroup wrote it (their order follows the list's)
             assert torch.equal(torch.sort(again["loss_partial"]).values, torch.sort(lp_f).values)
+
+
+def _step_buffers(lib, N, K, D, dev, layout, HW):
+    """Caller-owned work buffers of vq_quantize_step, sized by the library's own helpers."""
+    u8 = lambda n: torch.empty(max(int(n), 16), dtype=torch.uint8, device=dev)
+    nslab = lib.vq_scatter_slabs_for(N, K, D, layout, HW)
+    return {"image": u8(lib.vq_image_bytes(K, D)), "e2": u8(lib.vq_norms_bytes(K)),
+            "control": torch.zeros(16, dtype=torch.int32, device=dev), "idx32": torch.empty(N, dtype=torch.int32, device=dev),
+            "nf_rows": torch.empty(N, dtype=torch.int32, device=dev), "loss_partial": u8(lib.vq_loss_partial_bytes(N)),
+            "split": u8(lib.vq_search_split_bytes(N, K)), "counts": torch.zeros(2, K, dtype=torch.int32, device=dev),
+            "slabs": torch.empty(nslab * K * D, dtype=torch.float32, device=dev), "nslab": nslab}
+
+
+def test_whole_forward_through_one_c_call(dev, ops):
+    """vq_quantize_step, bound by hand as a C caller would (plain pointers in a struct): two training steps and
+    an eval step of configuration 1 against the oracle's forward (vqvae/ema_vector_quantizer.py:33-108)."""
+    import ctypes
+    from vq_vae_amd import _lib
+    lib = _lib.load()
+    K, D, shape = 512, 64, (16, 64, 16, 16)
+    N, HW = shape[0] * shape[2] * shape[3], shape[2] * shape[3]
+    E0 = gauss(2201, (K, D))
+    st = vo.OracleState.fresh(E0)
+    E = torch.from_numpy(E0).to(dev)
+    ema_w, cluster, usage = torch.zeros(K, D, device=dev), torch.zeros(K, device=dev), torch.zeros(K, device=dev)
+    b = _step_buffers(lib, N, K, D, dev, 1, HW)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    a = _lib.StepArgs()
+    a.layout, a.N, a.D, a.HW, a.K = 1, N, D, HW, K
+    a.E, a.ema_w, a.cluster_size, a.usage = E.data_ptr(), ema_w.data_ptr(), cluster.data_ptr(), usage.data_ptr()
+    a.decay, a.one_minus_decay, a.eps, a.k_eps = ops.ema_scalars(K, 0.95, 1e-5)
+    a.beta, a.temperature = 3.0, 1.0
+    a.image, a.e2, a.control, a.idx32, a.nf_rows = (b[k].data_ptr() for k in ("image", "e2", "control", "idx32", "nf_rows"))
+    a.loss_partial, a.split_ws, a.slabs, a.nslab, a.sort_work = b["loss_partial"].data_ptr(), b["split"].data_ptr(), b["slabs"].data_ptr(), b["nslab"], None
+    a.dmin = None
+    for step, training in enumerate((True, True, False)):
+        z_np = gauss(2210 + step, shape)
+        z = torch.from_numpy(z_np).to(dev)
+        idx64 = torch.empty(N, dtype=torch.int64, device=dev)
+        q = torch.empty_like(z)
+        scal = torch.empty(2, device=dev)
+        a.z, a.training = z.data_ptr(), 1 if training else 0
+        a.idx64, a.q_out, a.loss_out, a.perplexity_out = idx64.data_ptr(), q.data_ptr(), scal.data_ptr(), scal.data_ptr() + 4
+        a.counts, a.counts_next = b["counts"][step % 2].data_ptr(), b["counts"][1 - step % 2].data_ptr()
+        a.control_clean = 0 if step == 0 else 1          # the previous vq_quantize_step left both clean
+        assert lib.vq_quantize_step(ctypes.byref(a), stream) == 0
+        torch.cuda.synchronize()
+        r = vo.forward(z_np, st, 3.0, 0.95, 1e-5, 1.0, training)
+        assert np.array_equal(idx64.cpu().numpy(), r["indices"].ravel())
+        assert np.array_equal(_bits(q.cpu().numpy()), _bits(r["quantized"]))
+        assert abs(float(scal[0]) - r["loss"]) <= 1e-5 * abs(r["loss"])
+        assert abs(float(scal[1]) - r["perplexity"]) <= 1e-5 * r["perplexity"]
+        assert rel_err(E.cpu().numpy(), st.embedding) <= 1e-5 and rel_err(ema_w.cpu().numpy(), st.ema_w) <= 1e-5
+        assert rel_err(cluster.cpu().numpy(), st.ema_cluster_size) <= 1e-5
+        assert np.array_equal(usage.cpu().numpy(), st.usage_count)
+
+
+def test_packed_statistics_of_two_ranks_through_the_c_calls(dev, ops):
+    """The data-parallel exchange as a C caller drives it: two "ranks" (two batches on the one GPU) search, count and
+    scatter, vq_pack_stats packs each rank's statistics, the two buffers are added (what the SUM all-reduce does),
+    and each rank finishes with vq_step_finish_reduced + vq_ema_codebook_update_end.  Both replicas end bit-identical
+    and equal to the oracle's step on the concatenated batch; each rank's loss is its own batch's."""
+    import ctypes
+    from vq_vae_amd import _lib
+    lib = _lib.load()
+    K, D, shape = 512, 64, (8, 64, 16, 16)
+    N, HW = shape[0] * shape[2] * shape[3], shape[2] * shape[3]
+    E0 = gauss(2301, (K, D))
+    zs = [gauss(2310 + r, shape) for r in range(2)]
+    st = vo.OracleState.fresh(E0)
+    ref = vo.forward(np.concatenate(zs, 0), st, 3.0, 0.95, 1e-5, 1.0, True)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    d, omd, eps, keps = ops.ema_scalars(K, 0.95, 1e-5)
+    nfl = lib.vq_packed_stats_floats(K, D, 1)
+    ranks = []
+    for r in range(2):
+        ws = ops.Workspace(dev)
+        z = torch.from_numpy(zs[r]).to(dev)
+        E = torch.from_numpy(E0).to(dev)
+        res = ops.search(z, E, ws, want_quantized=True)
+        counts = torch.zeros(K, dtype=torch.int32, device=dev)
+        assert lib.vq_code_histogram(p(res["idx32"]), 0, N, K, p(counts), 1, p(res["control"]), stream) == 0
+        slabs, nslab = ops.embed_sums(z, res["idx32"], K, ws, zmax_valid=True)
+        buf = torch.empty(nfl, dtype=torch.float32, device=dev)
+        assert lib.vq_pack_stats(p(slabs), nslab, K, D, p(counts), N, p(buf), stream) == 0
+        ranks.append({"ws": ws, "E": E, "ema_w": torch.zeros(K, D, device=dev), "cluster": torch.zeros(K, device=dev), "usage": torch.zeros(K, device=dev),
+                      "res": res, "lp": res["loss_partial"].clone(), "n_partial": res["n_partial"], "buf": buf,
+                      "idx": res["indices"].clone()})
+    reduced = ranks[0]["buf"] + ranks[1]["buf"]              # SUM all-reduce
+    losses = []
+    for r in ranks:
+        buf = reduced.clone()
+        scal = torch.empty(2, device=dev)
+        counts64 = torch.empty(K, dtype=torch.int64, device=dev)
+        ntot = torch.empty(1, dtype=torch.int64, device=dev)
+        assert lib.vq_step_finish_reduced(p(r["lp"]), r["n_partial"], N, D, 3.0, ctypes.c_void_p(buf.data_ptr() + K * D * 4), K,
+                                          d, omd, eps, keps, p(r["usage"]), p(r["cluster"]), p(scal), ctypes.c_void_p(scal.data_ptr() + 4),
+                                          p(counts64), p(ntot), None, None, stream) == 0
+        assert lib.vq_ema_codebook_update_end(p(buf), 1, K, D, d, omd, p(r["cluster"]), p(r["ema_w"]), p(r["E"]), None, None, stream) == 0
+        torch.cuda.synchronize()
+        assert int(ntot) == 2 * N and np.array_equal(counts64.cpu().numpy(), ref["counts"].astype(np.int64))
+        assert abs(float(scal[1]) - ref["perplexity"]) <= 1e-5 * ref["perplexity"]
+        losses.append(float(scal[0]))
+    a, b = ranks
+    for k in ("E", "ema_w", "cluster", "usage"):
+        assert torch.equal(a[k].view(torch.int32), b[k].view(torch.int32)), k
+    assert rel_err(a["E"].cpu().numpy(), st.embedding) <= 1e-5 and rel_err(a["ema_w"].cpu().numpy(), st.ema_w) <= 1e-5
+    assert rel_err(a["cluster"].cpu().numpy(), st.ema_cluster_size) <= 1e-5
+    assert np.array_equal(a["usage"].cpu().numpy(), st.usage_count)
+    assert np.array_equal(np.concatenate([a["idx"].cpu().numpy(), b["idx"].cpu().numpy()]), ref["indices"].ravel())
+    assert abs(sum(losses) / 2 - ref["loss"]) <= 1e-5 * abs(ref["loss"])      # equal batches: the mean of the two local means
