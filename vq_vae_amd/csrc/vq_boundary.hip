@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void vq_gather_project_kernel(const float* __r
           for (int q = 0; q < 4; ++q) ev[q] = e[4 * c16 + q];
           float zv[16];
 #pragma unroll
-          for (int i = 0; i < 16; ++i) zv[i] = z[zoff + (int64_t)(16 * c16 + i) * HW];
+          for (int i = 0; i < 16; ++i) zv[i] = __builtin_nontemporal_load(&z[zoff + (int64_t)(16 * c16 + i) * HW]);   // streams: kept from displacing the table rows in L2
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const float diff = ev[i >> 2][i & 3] - zv[i];
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void vq_gather_project_kernel(const float* __r
 #pragma unroll
           for (int q = 0; q < 4; ++q) pv[q] = p[4 * c16 + q];
 #pragma unroll
-          for (int i = 0; i < 16; ++i) out[ooff + (int64_t)(16 * c16 + i) * HW] = pv[i >> 2][i & 3];
+          for (int i = 0; i < 16; ++i) __builtin_nontemporal_store(pv[i >> 2][i & 3], &out[ooff + (int64_t)(16 * c16 + i) * HW]);
         }
       } else {
         const float* es = E + (size_t)k * D;
@@ -125,12 +125,12 @@ __global__ __launch_bounds__(256) void vq_backward_gather_kernel(const float* __
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int64_t o = off0 + (int64_t)(16 * c16 + i) * HW;
-          zv[i] = z[o];
-          gv[i] = grad_q ? grad_q[o] : 0.0f;
+          zv[i] = __builtin_nontemporal_load(&z[o]);
+          gv[i] = grad_q ? __builtin_nontemporal_load(&grad_q[o]) : 0.0f;
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-          grad_z[off0 + (int64_t)(16 * c16 + i) * HW] = gv[i] + gg * (zv[i] - ev[i >> 2][i & 3]);
+          __builtin_nontemporal_store(gv[i] + gg * (zv[i] - ev[i >> 2][i & 3]), &grad_z[off0 + (int64_t)(16 * c16 + i) * HW]);
       }
     } else {
       for (int c = 0; c < D; ++c) {

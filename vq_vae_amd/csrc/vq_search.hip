@@ -1921,14 +1921,16 @@ __global__ __launch_bounds__(256) void vq_gather_st_kernel(const float* __restri
           f32x4 ev[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) ev[q] = e[4 * c16 + q];
+          // (the latents and the outputs pass through once: non-temporal, so that they do not push the code rows
+          // out of L2 -- every row of the batch fetches one of K rows of E at random)
           float zv[16];
 #pragma unroll
-          for (int i = 0; i < 16; ++i) zv[i] = z[off0 + (int64_t)(16 * c16 + i) * HW];
+          for (int i = 0; i < 16; ++i) zv[i] = __builtin_nontemporal_load(&z[off0 + (int64_t)(16 * c16 + i) * HW]);
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const float diff = ev[i >> 2][i & 3] - zv[i];
             part = __builtin_fmaf(diff, diff, part);
-            q_out[off0 + (int64_t)(16 * c16 + i) * HW] = zv[i] + diff;
+            __builtin_nontemporal_store(zv[i] + diff, &q_out[off0 + (int64_t)(16 * c16 + i) * HW]);
           }
         }
       } else {
@@ -1939,6 +1941,40 @@ __global__ __launch_bounds__(256) void vq_gather_st_kernel(const float* __restri
           part = __builtin_fmaf(diff, diff, part);
           q_out[off0 + (int64_t)c * HW] = zv + diff;
         }
+      }
+    }
+  } else if ((D & 3) == 0 && ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(q_out) | reinterpret_cast<uintptr_t>(E)) & 15) == 0) {
+    // rows: a wave takes rows wave, wave + 4, ... of the block, four at a time; a lane moves 16 bytes of each
+    // (one wave instruction = 1 KiB = a whole row at D = 256); latents and outputs non-temporal as above
+    const int D4 = D >> 2;
+    for (int r = wave; r < VQ_WG_ROWS; r += 16) {
+      int64_t n[4], k[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        n[u] = row0 + r + 4 * u;
+        k[u] = n[u] < N ? idx[n[u]] : -1;
+        if (k[u] >= K) k[u] = -1;
+      }
+      for (int c4 = lane; c4 < D4; c4 += 64) {
+        f32x4 zv[4], ev[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (k[u] >= 0) {
+            zv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(z + n[u] * D) + c4);
+            ev[u] = reinterpret_cast<const f32x4*>(E + (size_t)k[u] * D)[c4];
+          }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (k[u] >= 0) {
+            f32x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float diff = ev[u][i] - zv[u][i];
+              part = __builtin_fmaf(diff, diff, part);
+              o[i] = zv[u][i] + diff;
+            }
+            __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(q_out + n[u] * D) + c4);
+          }
       }
     }
   } else {
