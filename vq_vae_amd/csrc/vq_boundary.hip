@@ -72,6 +72,45 @@ __global__ __launch_bounds__(256) void vq_gather_project_kernel(const float* __r
         for (int c = 0; c < DP; ++c) out[ooff + (int64_t)c * HW] = ps[c];
       }
     }
+  } else if (((D | DP) & 3) == 0 && ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(out) |
+                                      reinterpret_cast<uintptr_t>(E) | reinterpret_cast<uintptr_t>(P)) & 15) == 0) {
+    // rows: a wave takes rows wave, wave + 4, ... of the block, four at a time, 16 bytes per lane
+    // (one wave instruction = a whole row at 256 channels); latents and outputs non-temporal
+    const int D4 = D >> 2, DP4 = DP >> 2;
+    for (int r = wave; r < VQ_WG_ROWS; r += 16) {
+      int64_t n[4], k[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        n[u] = row0 + r + 4 * u;
+        k[u] = n[u] < N ? idx[n[u]] : -1;
+        if (k[u] >= K) k[u] = -1;
+      }
+      for (int c4 = lane; c4 < D4; c4 += 64) {
+        f32x4 zv[4], ev[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (k[u] >= 0) {
+            zv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(z + n[u] * D) + c4);
+            ev[u] = reinterpret_cast<const f32x4*>(E + (size_t)k[u] * D)[c4];
+          }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (k[u] >= 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float diff = ev[u][i] - zv[u][i];
+              part = __builtin_fmaf(diff, diff, part);
+            }
+          }
+      }
+      for (int c4 = lane; c4 < DP4; c4 += 64) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (k[u] >= 0)
+            __builtin_nontemporal_store(reinterpret_cast<const f32x4*>(P + (size_t)k[u] * DP)[c4],
+                                        reinterpret_cast<f32x4*>(out + n[u] * DP) + c4);
+      }
+    }
   } else {
     // a wave walks one row at a time, lanes along the channels
     for (int r = wave; r < VQ_WG_ROWS; r += 4) {
@@ -136,6 +175,38 @@ __global__ __launch_bounds__(256) void vq_backward_gather_kernel(const float* __
       for (int c = 0; c < D; ++c) {
         const int64_t o = off0 + (int64_t)c * HW;
         grad_z[o] = (grad_q ? grad_q[o] : 0.0f) + gg * (z[o] - es[c]);
+      }
+    }
+  } else if ((D & 3) == 0 && ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(grad_z) | reinterpret_cast<uintptr_t>(E) |
+                               reinterpret_cast<uintptr_t>(grad_q)) & 15) == 0) {
+    // rows, 16 bytes per lane, four rows of the block in flight per wave (see vq_gather_project_kernel)
+    const int D4 = D >> 2;
+    for (int r = wave; r < VQ_WG_ROWS; r += 16) {
+      int64_t n[4], k[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        n[u] = row0 + r + 4 * u;
+        k[u] = n[u] < N ? idx[n[u]] : -2;          // -2: no such row; -1 or beyond K: a row that passes grad_q through
+        if (k[u] >= K) k[u] = -1;
+      }
+      for (int c4 = lane; c4 < D4; c4 += 64) {
+        f32x4 zv[4], ev[4], gv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (k[u] != -2) {
+            zv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(z + n[u] * D) + c4);
+            gv[u] = grad_q ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grad_q + n[u] * D) + c4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            ev[u] = reinterpret_cast<const f32x4*>(E + (size_t)(k[u] >= 0 ? k[u] : 0) * D)[c4];
+          }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (k[u] != -2) {
+            const float gg = k[u] >= 0 ? g : 0.0f;
+            f32x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = gv[u][i] + gg * (zv[u][i] - ev[u][i]);
+            __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(grad_z + n[u] * D) + c4);
+          }
       }
     }
   } else {
