@@ -148,6 +148,21 @@ extern "C" int vq_pairwise_search_launch(const float* E, const float* image, con
                                          int32_t* control, void* stream);
 
 // Internal (not in the public header): knobs of the persistent short-sweep search (vq_search.hip).
+// LDS-DMA of 1 KiB pieces (16 bytes per lane) through a buffer descriptor: piece I of a run lies at
+// "descriptor + soff + I KiB + lane x 16" in memory and at "l + I KiB + lane x 16" in LDS; four consecutive pieces
+// share the scalar offset and M0 and differ in the instruction's immediate only, so that a DMA instruction needs
+// no vector instruction beside it.  `count` (wave-uniform) cuts the run short.
+template <int IMM>
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, float* l, uint32_t voff, uint32_t soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)l, 16, voff, soff, IMM, 0);
+}
+template <int I, int N>
+__device__ __forceinline__ void dma_run(__amdgpu_buffer_rsrc_t r, float* l, uint32_t voff, uint32_t soff, int count) {
+  if constexpr (I < N) {
+    if (I < count) dma16<(I % 4) * 1024>(r, l + (I / 4) * 1024, voff, soff + (I / 4) * 4096);
+    dma_run<I + 1, N>(r, l, voff, soff, count);
+  }
+}
 extern "C" int vq_internal_tune(int what, int value);
 
 // Internal (not in the public header): bf16 filter + exact verification (vq_filter.hip).

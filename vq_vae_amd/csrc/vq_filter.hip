@@ -223,20 +223,17 @@ struct FilterArgs {
 };
 
 template <int D>
-__device__ __forceinline__ void fq_stage_copy(const u32x4* image, int stage, char* lds_buf, int wave, int lane) {
+__device__ __forceinline__ void fq_stage_copy(__amdgpu_buffer_rsrc_t image, int stage, char* lds_buf, int wave, int lane) {
   constexpr int PIECES = FQ_STAGE_TILES * (D / 16 + 1);
-  const char* src = reinterpret_cast<const char*>(image) + (size_t)stage * PIECES * 1024 + lane * 16;
-  // waves 0-3 issue the DMA (one per SIMD); their partners 4-7 start the stage's MFMAs at once
+  // waves 0-3 issue the DMA (one per SIMD); their partners 4-7 start the stage's MFMAs at once.  A wave takes a
+  // contiguous run of the stage's 1 KiB pieces (dma_run: no vector instruction per piece)
   constexpr int NL = 4;
+  constexpr int PER = (PIECES + NL - 1) / NL;
   if (wave >= NL) return;
-#pragma unroll
-  for (int i = 0; i < (PIECES + NL - 1) / NL; ++i) {
-    const int p = i * NL + wave;
-    if (p < PIECES) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)p * 1024),
-                                       (__attribute__((address_space(3))) void*)(lds_buf + p * 1024), 16, 0, 0);
-    }
-  }
+  const int first = wave * PER;
+  const int count = PIECES - first < PER ? PIECES - first : PER;
+  dma_run<0, PER>(image, reinterpret_cast<float*>(lds_buf) + first * 256, (uint32_t)lane * 16u,
+                  (uint32_t)stage * (uint32_t)(PIECES * 1024) + (uint32_t)first * 1024u, count);
 }
 
 // Insert the 16 keys of one finished accumulator tile into the lane's sorted R smallest.
@@ -293,7 +290,8 @@ __global__ __launch_bounds__(512, 2) void vqf_filter_kernel(FilterArgs a) {
   if (threadIdx.x < D) mus[threadIdx.x] = a.mu[threadIdx.x];
   __syncthreads();
 
-  fq_stage_copy<D>(a.image, st_begin, flds, wave, lane);   // lands while z is being loaded
+  const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(a.image), 0, (int)((size_t)a.nstages * FQ_STAGE_TILES * FS * 1024), 0x00020000);
+  fq_stage_copy<D>(img, st_begin, flds, wave, lane);   // lands while z is being loaded
 
   float hmax[5];
 #pragma unroll
@@ -412,7 +410,7 @@ __global__ __launch_bounds__(512, 2) void vqf_filter_kernel(FilterArgs a) {
   int cur = 0;
   for (int st = st_begin; st < st_end; ++st) {
     char* buf = flds + cur * STAGE_B;
-    if (st + 1 < st_end) fq_stage_copy<D>(a.image, st + 1, flds + (cur ^ 1) * STAGE_B, wave, lane);
+    if (st + 1 < st_end) fq_stage_copy<D>(img, st + 1, flds + (cur ^ 1) * STAGE_B, wave, lane);
     const u32x4* A = reinterpret_cast<const u32x4*>(buf) + lane;
 #pragma unroll
     for (int t = 0; t < FQ_STAGE_TILES; ++t) {

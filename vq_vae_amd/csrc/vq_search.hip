@@ -110,17 +110,6 @@ __device__ __forceinline__ void stage_copy(const float* image, int stage, float*
 // instruction beside it (the pointer form spends a 64-bit vector add per piece, and the piece addresses, hoisted
 // out of the stage loop, live in scalar registers that spill), only two scalar adds per four pieces.  Vector
 // instructions are what a loader wave must not spend: they issue in the gaps of its SIMD partner's MFMAs.
-template <int IMM>
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, float* l, uint32_t voff, uint32_t soff) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)l, 16, voff, soff, IMM, 0);
-}
-template <int I, int N>
-__device__ __forceinline__ void dma_run(__amdgpu_buffer_rsrc_t r, float* l, uint32_t voff, uint32_t soff, int count) {
-  if constexpr (I < N) {
-    if (I < count) dma16<(I % 4) * 1024>(r, l + (I / 4) * 1024, voff, soff + (I / 4) * 4096);
-    dma_run<I + 1, N>(r, l, voff, soff, count);
-  }
-}
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t image_rsrc(const float* image, int nstages, int D) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(image), 0, (int)((size_t)nstages * vq_stage_floats(D) * 4), 0x00020000);
 }
