@@ -89,15 +89,20 @@ int vq_codebook_prep(const float* E, int K, int D, float* image, float* e2, int3
  *   z            [N rows], layout as above, D channels; HW only used for NCHW
  *   E            [K][D] row major codebook (rows code_base .. code_base+K-1 of the full one)
  *   image, e2    from vq_codebook_prep for the same E
- *   temperature  distances are divided by it when != 1 (ref :49-50)
+ *   temperature  distances are divided by it when != 1 (ref :49-50).  Whole-codebook sweeps compare undivided
+ *                distances and divide the winner only: division by T > 0 is monotone, so the result -- index
+ *                and quotient -- is that of dividing every distance, and the few rows where a code before the
+ *                winner lies within rounding of it are redone with every distance divided (same bits)
  *   code_base    added to every stored index (codebook-row sharding)
  *   idx64        [N] int64 out (ref :53), may be NULL
  *   idx32        [N] int32 out, required (feeds histogram / scatter)
  *   dmin         [N] winning distance out, may be NULL
  *   q_out        quantized output in z's layout, may be NULL (then loss_partial unused)
  *   loss_partial [vq_loss_partial_bytes/4] per-workgroup sums of (q - z)^2, may be NULL
- *   nf_rows      [N] int32 scratch: rows routed to the exact path (non-finite input)
- *   control      control words (nf counter, codebook flag)
+ *   nf_rows      [N] int32 scratch: rows routed to the exact path -- rows that are not finite from the front
+ *                (count in control word 0), rows of a temperature sweep with a close earlier code from the
+ *                end backwards (count in control word 6)
+ *   control      control words (the two counters, codebook flag, max |z| for the EMA scatter)
  *   split_ws     vq_search_split_bytes(N, K) bytes of scratch, may be NULL.  With fewer than
  *                32 Ki rows the row tiles alone cannot fill 256 CUs, and up to 512 Ki rows the
  *                last round of row tiles can leave most of them idle (257 tiles: two rounds);
