@@ -259,15 +259,19 @@ __device__ __forceinline__ void fq_scan(const f32x16& c, uint32_t tilebits, uint
 
 // R (4 or 8) = keys kept per lane.  The first pass runs R = 4; rows whose list overflowed are
 // filtered again with R = 8 (list mode).
+#ifndef FQ_CT
+#define FQ_CT 2   // 32-latent column tiles per wave (4: four waves per workgroup, one per SIMD -- measured, see the design notes)
+#endif
 template <int D, bool NCHW, int R>
-__global__ __launch_bounds__(512, 2) void vqf_filter_kernel(FilterArgs a) {
+__global__ __launch_bounds__(1024 / FQ_CT, FQ_CT == 2 ? 2 : 1) void vqf_filter_kernel(FilterArgs a) {
+  constexpr int CT = FQ_CT;
   constexpr int ZS = D / 16, FS = ZS + 1;
   constexpr int STAGE_B = FQ_STAGE_TILES * FS * 1024;
   extern __shared__ __attribute__((aligned(16))) char flds[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 31, g = lane >> 5;
-  const int64_t row0 = (int64_t)blockIdx.x * FQ_WG_ROWS + wave * 64;
+  const int64_t row0 = (int64_t)blockIdx.x * FQ_WG_ROWS + wave * (32 * CT);
   if (a.control[VQ_CTL_CB_FLAG] != 0) return;  // the verify kernel flags every row
   const bool listed = a.row_list != nullptr;
   int64_t nrows = a.N;
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(512, 2) void vqf_filter_kernel(FilterArgs a) {
   // the codebook mean, through LDS (behind the two stage buffers); the barrier comes before the
   // first DMA is issued, so that it does not wait for that copy
   float* mus = reinterpret_cast<float*>(flds + 2 * STAGE_B);
-  if (threadIdx.x < D) mus[threadIdx.x] = a.mu[threadIdx.x];
+  for (int c = threadIdx.x; c < D; c += 1024 / CT) mus[c] = a.mu[c];
   __syncthreads();
 
   const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(a.image), 0, (int)((size_t)a.nstages * FQ_STAGE_TILES * FS * 1024), 0x00020000);
@@ -297,10 +301,10 @@ __global__ __launch_bounds__(512, 2) void vqf_filter_kernel(FilterArgs a) {
 #pragma unroll
   for (int i = 0; i < 5; ++i) hmax[i] = __uint_as_float(a.hdr[i]);
 
-  u32x4 zb[2][FS];
+  u32x4 zb[CT][FS];
   uint32_t zmax_bits = 0;  // max |z| (bit pattern), for the EMA scatter's fixed-point scale
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
+  for (int ct = 0; ct < CT; ++ct) {
     int64_t n = row0 + ct * 32 + j;
     if (n >= nrows) n = nrows - 1;
     if (listed) n = a.row_list[n];
@@ -399,9 +403,9 @@ __global__ __launch_bounds__(512, 2) void vqf_filter_kernel(FilterArgs a) {
 
   uint32_t maskv = FQ_KEY_MASK;
   asm volatile("" : "+v"(maskv));
-  float m[2][R];
+  float m[CT][R];
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct)
+  for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
     for (int i = 0; i < R; ++i) m[ct][i] = __builtin_inff();
 
@@ -414,25 +418,28 @@ __global__ __launch_bounds__(512, 2) void vqf_filter_kernel(FilterArgs a) {
     const u32x4* A = reinterpret_cast<const u32x4*>(buf) + lane;
 #pragma unroll
     for (int t = 0; t < FQ_STAGE_TILES; ++t) {
-      f32x16 c0, c1;
+      f32x16 c[CT];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { c0[i] = 0.0f; c1[i] = 0.0f; }
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c[ct][i] = 0.0f;
 #pragma unroll
       for (int s = 0; s < FS; ++s) {
         const bf16x8 af = __builtin_bit_cast(bf16x8, A[(t * FS + s) * 64]);
-        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, zb[0][s]), c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, zb[1][s]), c1, 0, 0, 0);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+          c[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, zb[ct][s]), c[ct], 0, 0, 0);
       }
       const uint32_t tilebits = (uint32_t)(st * FQ_STAGE_TILES + t) << 4;
-      fq_scan<R>(c0, tilebits, maskv, m[0]);
-      fq_scan<R>(c1, tilebits, maskv, m[1]);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) fq_scan<R>(c[ct], tilebits, maskv, m[ct]);
     }
     __syncthreads();  // every wave is done with buf; the DMA of stage st+1 has landed
     cur ^= 1;
   }
 
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
+  for (int ct = 0; ct < CT; ++ct) {
     const int64_t pos = row0 + ct * 32 + j;   // cand / rowaux are indexed by position (= row unless listed)
     if (pos < nrows) {
 #pragma unroll
@@ -668,7 +675,7 @@ int launch_filter(const FilterArgs& a, hipStream_t s) {
   int nsplit = 1, sps = a.nstages;
   if (a.row_list) nsplit = a.nstages / 2 < FQ_MAX_SPLIT_LIST ? (a.nstages / 2 > 0 ? a.nstages / 2 : 1) : FQ_MAX_SPLIT_LIST;
   else fq_split(blocks, a.nstages, nsplit, sps);
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)nsplit), dim3(512), lds_bytes, s, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)nsplit), dim3(1024 / FQ_CT), lds_bytes, s, a);
   return vq_hip_status(hipGetLastError());
 }
 
