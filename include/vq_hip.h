@@ -43,14 +43,16 @@ int vq_version(void);
 const char* vq_status_string(int status);
 
 /*
- * Optional one-time set-up of a device, for callers that record the entry points into a HIP graph
- * or must keep the first timed call free of set-up work.  No counterpart in the reference.  For GPU
+ * Optional one-time set-up of a device, for callers that must keep the first call free of set-up
+ * work.  No counterpart in the reference.  For GPU
  * `device` it raises the dynamic-LDS limit of every kernel of the library that needs more than the
  * 64 KiB default (hipFuncSetAttribute) and looks up the device address of the library's static
  * scratch array (vq_pairwise_stats_static).  Without this call each entry point does the same for
- * its own kernels the first time it runs on a device -- host-side work that must not fall inside a
- * stream capture.  The call makes `device` current while it runs and restores the caller's current
- * device; it allocates nothing and may be repeated.
+ * its own kernels the first time it runs on a device.  The call makes `device` current while it runs
+ * and restores the caller's current device; it allocates nothing and may be repeated.
+ * (Recording the step's entry points into a HIP graph has been tried with this set-up done first and
+ * is NOT supported: replays of a captured vq_quantize_step returned wrong indices and faulted.  Only
+ * vq_pairwise_stats_static is written for use under capture.)
  */
 int vq_init(int device);
 /* Number of kernels vq_init prepares (entered in the library's table when it is loaded); diagnostic. */
