@@ -53,8 +53,8 @@ static inline int vq_hip_status(hipError_t e) { return e == hipSuccess ? VQ_OK :
 // Such a kernel needs hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per device before its
 // first launch.  Every launcher goes through vq_lds_ready<kernel, bytes>(): the kernel is entered
 // in a process-wide table when the library is loaded (static registration), the attribute is set
-// on the first launch on a device -- or up front for all kernels by vq_init(device), which is what a
-// caller does before stream capture, where the first-launch path would run inside the capture.
+// on the first launch on a device -- or up front for all kernels by vq_init(device), which keeps
+// the first call of every entry point free of this host-side work.
 void vq_lds_register(const void* kern, int bytes);
 int vq_lds_ensure(const void* kern, int bytes, int* dev_out);
 struct VqLdsRegistrar {
