@@ -617,8 +617,10 @@ __global__ __launch_bounds__(512 / CT, 2 / CT) void vq_search_mfma_kernel(Search
 // resident: 2 steps 0.54 ms, 1 step 0.50 ms): every instruction of a memory step issues between two of
 // the partner's MFMAs, so a step costs the partner little but lasts long, and the fewer steps a wave
 // spends outside its sweep, the fewer stages its partner sweeps alone.
-// cache policy of the latents' loads and the outputs' stores (the aux operand of the buffer instructions; bit 1 =
-// non-temporal): they pass through once, and left to the default they push the codebook image out of L2
+// cache policy of the latents' loads and the outputs' stores in NCHW (the aux operand of the buffer instructions;
+// bit 1 = non-temporal): they pass through once, and left to the default they push the codebook image out of L2.
+// Not for row-major latents: there a wave instruction touches 32 bytes of each of 32 rows, and without L2 to gather
+// such pieces into lines the same kernel ran 1.18 instead of 0.70 ms at K = 64, D = 256
 #ifndef VQ_CYC_STREAM
 #define VQ_CYC_STREAM 2   // measured at K = 8192, D = 256, 4 Mi rows: 20.0 -> 16.5 GB read past L2 per launch; K = 512: 8.94 -> 8.81 ms
 #endif
@@ -822,7 +824,7 @@ __global__ __launch_bounds__(512, 2) void vq_search_cyclic_kernel(SearchArgs a, 
           half_deinterleave(o);
           // a row is written whole: rows that are not finite get their values from the exact kernel
           // afterwards; rows past the end are not written
-          if (valid) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), orsrc, loff, gq * bstride, VQ_CYC_STREAM);
+          if (valid) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), orsrc, loff, gq * bstride, 0);
         }
       } else if (okf) {   // one predicated region: rows past the end and non-finite rows write nothing
 #pragma unroll
@@ -846,7 +848,7 @@ __global__ __launch_bounds__(512, 2) void vq_search_cyclic_kernel(SearchArgs a, 
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int gq = M * U + u;
-          const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zrsrc, loff, gq * bstride, VQ_CYC_STREAM));
+          const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zrsrc, loff, gq * bstride, 0));
 #pragma unroll
           for (int q = 0; q < 4; ++q) zr[4 * gq + q] = v[q];
         }
