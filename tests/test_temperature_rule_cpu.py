@@ -114,3 +114,23 @@ def test_overflowing_and_vanishing_quotients_are_close():
     tiny = np.array([[3e-45, 1e-45, 5.0] + [9.0] * 61], np.float32)
     _, _, near = deferred(tiny, 100.0, 0)       # quotients below the smallest subnormal: both round to zero
     assert near.all() and literal(tiny, 100.0)[0][0] == 0
+
+
+def test_quotient_index_keys_order_as_the_argmin_does():
+    """Rows that several workgroups share fold their winners with an unsigned 64-bit minimum over keys
+    (quotient bits made order-preserving) << 32 | index: smaller quotient first, lower index on equal quotients."""
+    rng = np.random.default_rng(5)
+    q = np.concatenate([rng.standard_normal(2000).astype(np.float32) * np.float32(10.0 ** rng.uniform(-30, 30)),
+                        np.array([0.0, np.inf, -np.inf, 1e-45, -1e-45, 3.4e38, -3.4e38], np.float32)])
+    q = np.where(q == 0, np.float32(0.0), q)          # the kernels never see -0 (a sum of opposite terms rounds to +0)
+    idx = rng.integers(0, 1 << 20, q.size)
+    u = q.view(np.uint32).astype(np.uint64)
+    u = np.where(u >> np.uint64(31), u ^ np.uint64(0xFFFFFFFF), u ^ np.uint64(0x80000000))
+    key = (u << np.uint64(32)) | idx.astype(np.uint64)
+    order = np.argsort(key, kind="stable")
+    want = np.lexsort((idx, q))                         # by quotient, then by index
+    assert np.array_equal(q[order], q[want]) and np.array_equal(idx[order], idx[want])
+    # and the quotient comes back bit for bit
+    back = key >> np.uint64(32)
+    back = np.where(back >> np.uint64(31), back ^ np.uint64(0x80000000), back ^ np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    assert np.array_equal(back.view(np.float32).view(np.uint32), q.view(np.uint32))
